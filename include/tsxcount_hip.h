@@ -1,0 +1,170 @@
+/*
+ * tsxcount_hip.h -- C ABI of libtsxcount_hip.so, the MI355X (gfx950) k-mer
+ * counting hash map that backs tsxCount's --mode=HIP.
+ *
+ * Every entry point is what a TSXHashMap subclass in the reference would bind
+ * for this path; the reference interface each one replaces is cited as
+ * file:line of mjoppich/tsxCount.  Plain pointers and sizes only.  All
+ * functions return TSX_HIP_OK (0) or a negative TSX_HIP_E* code; none of them
+ * falls back to a CPU path -- without a GPU they fail with TSX_HIP_ENODEVICE.
+ *
+ * k-mers cross the boundary 2-bit encoded exactly like UBigInt holds them in
+ * the reference (src/utils/SequenceUtils.h:86-160): base i of the k-mer sits
+ * in bits 2i,2i+1 (A=0 C=1 G=2 T=3), packed little-endian into
+ * tsx_hip_key_limbs(k) = ceil(2k/64) uint64 limbs per k-mer.
+ */
+#ifndef TSXCOUNT_HIP_H
+#define TSXCOUNT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsx_hip_map tsx_hip_map; /* opaque: one table on one GPU */
+
+enum {
+    TSX_HIP_OK = 0,
+    TSX_HIP_EINVAL = -1,    /* bad argument; 2k <= l mirrors TSXException (TSXHashMap.h:91-94) */
+    TSX_HIP_ENODEVICE = -2, /* no usable HIP device */
+    TSX_HIP_ENOMEM = -3,    /* device allocation failed */
+    TSX_HIP_EHIP = -4,      /* a HIP runtime call failed (see tsx_hip_last_error) */
+    TSX_HIP_EFULL = -5,     /* a k-mer could not be placed: reference exit(42), TSXHashMap.h:340-343 */
+    TSX_HIP_EOVERFLOW = -6, /* the secondary (count overflow) array is full */
+    TSX_HIP_ERANGE = -7     /* output buffer too small */
+};
+
+/* Layout the library derived from (k, l, storagebits); see DESIGN.md. */
+typedef struct tsx_hip_layout {
+    int32_t k, l;           /* as given */
+    int32_t key_limbs;      /* ceil(2k/64): limbs per k-mer at the boundary */
+    int32_t entry_limbs;    /* uint64 limbs per table slot */
+    int32_t func_bits;      /* 2k-l hashed-key bits stored in the slot (TSXTypes.h:39) */
+    int32_t reprobe_bits;   /* width of the reprobe field stored next to them */
+    int32_t count_bits;     /* in-slot counter width ("storage bits", TSXHashMap.h:83) */
+    int32_t overflow_l;     /* log2 slots of the secondary overflow array */
+    uint32_t max_reprobes;  /* probes tried before TSX_HIP_EFULL */
+    uint64_t slots;         /* 2^l (getMaxElements, TSXHashMap.h:162) */
+    uint64_t table_bytes;   /* device bytes of the primary table */
+} tsx_hip_layout;
+
+/* Counters kept on the device; print_stats()/main.cpp:479-501 equivalents. */
+typedef struct tsx_hip_stats {
+    uint64_t kmers_added;      /* k-mer occurrences inserted ("add calls") */
+    uint64_t insert_failures;  /* occurrences lost to TSX_HIP_EFULL */
+    uint64_t overflow_carries; /* carries pushed to the secondary array */
+    uint64_t overflow_failures;/* carries lost to TSX_HIP_EOVERFLOW */
+    uint64_t distinct;         /* occupied slots = getKmerCount() (TSXHashMap.h:645) */
+    uint64_t overflow_used;    /* occupied secondary slots */
+    uint64_t lock_timeouts;    /* multi-limb claim spins that gave up (must be 0) */
+} tsx_hip_stats;
+
+int tsx_hip_key_limbs(int k);
+const char *tsx_hip_strerror(int code);
+const char *tsx_hip_last_error(void); /* text of the last HIP runtime failure in this thread */
+int tsx_hip_device_count(void);
+
+/* TSXSeqUtils::fromSequence (SequenceUtils.h:86-160).  Non-ACGT bytes get the
+ * fixed code ((b>>1)^(b>>2))&3 where the reference draws rand()%2 bits.      */
+int tsx_hip_encode(const char *seq, int k, uint64_t *limbs_out);
+/* TSXSeqUtils::toSequence (SequenceUtils.h:47-84). out must hold k+1 bytes. */
+int tsx_hip_decode(const uint64_t *limbs, int k, char *out);
+
+/*
+ * TSXHashMap(iL, iStorageBits, iK) (TSXHashMap.h:79-154) and
+ * TSXHashMapCAS(iL, iStorageBits, iK, iThreads) (TSXHashMapCAS.h:239-245).
+ *   storagebits  0 = widest counter that fits the slot; 1..32 = exactly that
+ *                many in-slot bits, larger counts carry into the secondary
+ *                array (the reference chains overflow slots instead,
+ *                TSXHashMapPerf.h:699-881).
+ *   overflow_l   log2 slots of the secondary array; 0 = max(10, l-4).
+ *   hash_seed    seed of the bijective GF(2) mapping; the reference draws it
+ *                from time(NULL) (BijectiveKMapping.h:84).
+ *   device       HIP device ordinal.
+ */
+int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
+                   uint64_t hash_seed, int device);
+void tsx_hip_destroy(tsx_hip_map *m);
+int tsx_hip_get_layout(const tsx_hip_map *m, tsx_hip_layout *out);
+/* Zero the table, the secondary array and the counters. */
+int tsx_hip_clear(tsx_hip_map *m);
+/* Wait for everything queued on the map's stream and report sticky errors
+ * (TSX_HIP_EFULL / TSX_HIP_EOVERFLOW) raised by earlier inserts.            */
+int tsx_hip_sync(tsx_hip_map *m);
+
+/*
+ * countKMers (src/mains/main.cpp:104-218): FASTXreader<FASTQEntry>::getEntries
+ * (FastXReader.h:221-280,307-385) + createKMers (testExecution.h:15-36) +
+ * fromSequence + addKmer, for one whole FASTQ text.  Empty lines are skipped,
+ * every 4 remaining lines are a record, line 2 is the sequence, every window
+ * of k bytes of it is one k-mer.
+ *
+ * _host copies `n` bytes from host memory through pinned staging buffers.
+ * _device takes a device pointer (16-byte aligned, text starts at a record
+ * boundary), queues the work on `stream` (a hipStream_t, NULL = the map's own
+ * stream) and returns without waiting; call tsx_hip_sync before reading.
+ */
+int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n);
+int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream);
+
+/*
+ * TSXHashMap::addKmer (TSXHashMap.h:182; CAS variant TSXHashMapCAS.h:268) for
+ * a batch of n encoded k-mers; counts == NULL adds 1 per k-mer, otherwise
+ * counts[i] occurrences (used by the multi-GPU merge).
+ */
+int tsx_hip_add_kmers_host(tsx_hip_map *m, const uint64_t *kmers, const uint64_t *counts, size_t n);
+int tsx_hip_add_kmers_device(tsx_hip_map *m, const void *dev_kmers, const void *dev_counts, size_t n,
+                             void *stream);
+
+/* TSXHashMap::getKmerCount(kmer) (TSXHashMap.h:548-638) for n k-mers. */
+int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out);
+int tsx_hip_get_counts_device(tsx_hip_map *m, const void *dev_kmers, size_t n, void *dev_counts_out,
+                              void *stream);
+
+/* getKmerCount() / print_stats() / iAddKmerCount (TSXHashMap.h:645,390; main.cpp:486-500). */
+int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out);
+
+/*
+ * TSXHashMap::getAllKmers (TSXHashMap.h:660-722) plus each k-mer's count.
+ * _device writes up to cap entries into device buffers (kmers: cap*key_limbs
+ * uint64, counts: cap uint64) and the number written to *dev_n (uint64);
+ * order is unspecified.  _host sizes with tsx_hip_get_stats().distinct.
+ */
+int tsx_hip_dump_host(tsx_hip_map *m, uint64_t *kmers_out, uint64_t *counts_out, size_t cap,
+                      size_t *n_out);
+int tsx_hip_dump_device(tsx_hip_map *m, void *dev_kmers_out, void *dev_counts_out, size_t cap,
+                        void *dev_n, void *stream);
+/*
+ * Multi-GPU merge, sender side: like dump_device, but entries are grouped by
+ * owner rank = tsx_hip_owner(kmer, nranks) into nranks contiguous segments;
+ * dev_seg_counts (nranks uint64) receives the segment sizes.  The segments
+ * travel through an RCCL all-to-all and are inserted on the owner with
+ * tsx_hip_add_kmers_device.  cap must be >= distinct.
+ */
+int tsx_hip_partition_device(tsx_hip_map *m, int nranks, void *dev_kmers_out, void *dev_counts_out,
+                             size_t cap, void *dev_seg_counts, void *stream);
+int tsx_hip_owner_host(const tsx_hip_map *m, const uint64_t *kmer, int nranks);
+
+/* IBijectiveFunction::apply / inv_apply (IBijectiveFunction.h:26-27) on the host,
+ * and the matrix rows (row i <-> output bit 2k-1-i, BijectiveKMapping.h:202-256). */
+int tsx_hip_hash_apply(const tsx_hip_map *m, const uint64_t *kmer, uint64_t *key_out);
+int tsx_hip_hash_invert(const tsx_hip_map *m, const uint64_t *key, uint64_t *kmer_out);
+int tsx_hip_hash_rows(const tsx_hip_map *m, uint64_t *rows_out /* 2k x key_limbs */);
+
+/*
+ * Synthetic reads shaped like generateFakeSequences.py (500-1000 random bases
+ * + 100-300 'A', '@seq<i>' header, '&' qualities), written as FASTQ text
+ * straight into device memory.  Sizing call: dev_out == NULL returns the byte
+ * count in *bytes_out and the number of k-mers (for k) in *kmers_out.
+ * tsxcount_amd/synth.py is the same generator on the host (numpy).
+ */
+int tsx_hip_synth_fastq_device(uint64_t seed, uint64_t first_read, uint64_t n_reads, int k,
+                               void *dev_out, size_t cap, uint64_t *bytes_out, uint64_t *kmers_out,
+                               uint64_t *polya_kmers_out, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSXCOUNT_HIP_H */

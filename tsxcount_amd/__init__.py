@@ -1,0 +1,281 @@
+"""tsxcount_amd -- MI355X (gfx950) k-mer counting hash map behind tsxCount's --mode=HIP.
+
+The product is ``lib/libtsxcount_hip.so`` (hand-written HIP, C ABI in
+``include/tsxcount_hip.h``).  This module is the thin host-side mirror of the
+reference's ``TSXHashMap`` surface over that ABI (ctypes), used by the tests
+and the bench.  There is no CPU fallback: without the built library the
+import fails, and without a GPU ``TSXHashMapHIP(...)`` raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtsxcount_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsxcount_hip.h")
+
+OK, EINVAL, ENODEVICE, ENOMEM, EHIP, EFULL, EOVERFLOW, ERANGE = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class TSXException(RuntimeError):
+    """Mirror of TSXException (TSXHashMap.h:28-47); carries the C-ABI code."""
+
+    def __init__(self, code, what):
+        super().__init__(what)
+        self.code = code
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int32), ("l", ctypes.c_int32), ("key_limbs", ctypes.c_int32),
+                ("entry_limbs", ctypes.c_int32), ("func_bits", ctypes.c_int32),
+                ("reprobe_bits", ctypes.c_int32), ("count_bits", ctypes.c_int32),
+                ("overflow_l", ctypes.c_int32), ("max_reprobes", ctypes.c_uint32),
+                ("slots", ctypes.c_uint64), ("table_bytes", ctypes.c_uint64)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("kmers_added", ctypes.c_uint64), ("insert_failures", ctypes.c_uint64),
+                ("overflow_carries", ctypes.c_uint64), ("overflow_failures", ctypes.c_uint64),
+                ("distinct", ctypes.c_uint64), ("overflow_used", ctypes.c_uint64),
+                ("lock_timeouts", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {f: int(getattr(self, f)) for f, _ in self._fields_}
+
+
+def build():
+    """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "all"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    """Load libtsxcount_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("tsxcount_amd: %s is missing; run tsxcount_amd.build() "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, sz, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_size_t, ctypes.c_int
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    L.tsx_hip_strerror.restype = ctypes.c_char_p
+    L.tsx_hip_strerror.argtypes = [ci]
+    L.tsx_hip_last_error.restype = ctypes.c_char_p
+    L.tsx_hip_key_limbs.argtypes = [ci]
+    L.tsx_hip_encode.argtypes = [ctypes.c_char_p, ci, u64p]
+    L.tsx_hip_decode.argtypes = [u64p, ci, ctypes.c_char_p]
+    L.tsx_hip_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, u64, ci]
+    L.tsx_hip_destroy.argtypes = [vp]
+    L.tsx_hip_destroy.restype = None
+    L.tsx_hip_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]
+    L.tsx_hip_clear.argtypes = [vp]
+    L.tsx_hip_sync.argtypes = [vp]
+    L.tsx_hip_count_fastq_host.argtypes = [vp, ctypes.c_char_p, sz]
+    L.tsx_hip_count_fastq_device.argtypes = [vp, vp, sz, vp]
+    L.tsx_hip_add_kmers_host.argtypes = [vp, u64p, u64p, sz]
+    L.tsx_hip_add_kmers_device.argtypes = [vp, vp, vp, sz, vp]
+    L.tsx_hip_get_counts_host.argtypes = [vp, u64p, sz, u64p]
+    L.tsx_hip_get_counts_device.argtypes = [vp, vp, sz, vp, vp]
+    L.tsx_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.tsx_hip_dump_host.argtypes = [vp, u64p, u64p, sz, ctypes.POINTER(sz)]
+    L.tsx_hip_dump_device.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.tsx_hip_partition_device.argtypes = [vp, ci, vp, vp, sz, vp, vp]
+    L.tsx_hip_owner_host.argtypes = [vp, u64p, ci]
+    L.tsx_hip_hash_apply.argtypes = [vp, u64p, u64p]
+    L.tsx_hip_hash_invert.argtypes = [vp, u64p, u64p]
+    L.tsx_hip_hash_rows.argtypes = [vp, u64p]
+    L.tsx_hip_synth_fastq_device.argtypes = [u64, u64, u64, ci, vp, sz, u64p, u64p, u64p, ci, vp]
+    _lib = L
+    return L
+
+
+def _check(code):
+    if code != OK:
+        L = lib()
+        msg = L.tsx_hip_strerror(code).decode()
+        if code in (EHIP, ENODEVICE, ENOMEM):
+            extra = L.tsx_hip_last_error().decode()
+            if extra:
+                msg += " (" + extra + ")"
+        raise TSXException(code, msg)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+def key_limbs(k):
+    return (2 * k + 63) // 64
+
+
+def encode(seq, k=None):
+    """TSXSeqUtils::fromSequence (SequenceUtils.h:86-160) -> uint64 limbs."""
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    k = len(s) if k is None else k
+    out = np.zeros(key_limbs(k), dtype=np.uint64)
+    _check(lib().tsx_hip_encode(s, k, _p(out)))
+    return out
+
+
+def decode(limbs, k):
+    """TSXSeqUtils::toSequence (SequenceUtils.h:47-84)."""
+    a = np.ascontiguousarray(limbs, dtype=np.uint64)
+    buf = ctypes.create_string_buffer(k + 1)
+    _check(lib().tsx_hip_decode(_p(a), k, buf))
+    return buf.value.decode()
+
+
+def encode_many(seqs, k):
+    out = np.zeros((len(seqs), key_limbs(k)), dtype=np.uint64)
+    for i, s in enumerate(seqs):
+        out[i] = encode(s, k)
+    return out
+
+
+class TSXHashMapHIP:
+    """Host mirror of TSXHashMap / TSXHashMapCAS for --mode=HIP.
+
+    Constructor arguments follow TSXHashMap(iL, iStorageBits, iK)
+    (TSXHashMap.h:79); method names follow the reference class.
+    """
+
+    def __init__(self, iL, iStorageBits, iK, iThreads=0, hash_seed=1, overflow_l=0, device=0):
+        self._h = ctypes.c_void_p()
+        self._lib = lib()
+        _check(self._lib.tsx_hip_create(ctypes.byref(self._h), iK, iL, iStorageBits, overflow_l,
+                                        hash_seed, device))
+        self.layout = Layout()
+        _check(self._lib.tsx_hip_get_layout(self._h, ctypes.byref(self.layout)))
+        self.k, self.l, self.wk, self.device = iK, iL, self.layout.key_limbs, device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.tsx_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    @property
+    def handle(self):
+        return self._h
+
+    # --- reference surface -------------------------------------------------
+    def getK(self):
+        return self.k
+
+    def getMaxElements(self):
+        return int(self.layout.slots)
+
+    def addKmer(self, kmer):
+        """TSXHashMap::addKmer (TSXHashMap.h:182); kmer = limbs or sequence."""
+        self.addKmers(self._as_kmers([kmer]))
+        return True
+
+    def addKmers(self, kmers, counts=None):
+        a = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.wk)
+        c = None
+        if counts is not None:
+            c = np.ascontiguousarray(counts, dtype=np.uint64)
+            assert c.shape[0] == a.shape[0]
+        _check(self._lib.tsx_hip_add_kmers_host(self._h, _p(a), _p(c) if c is not None else None, a.shape[0]))
+
+    def getKmerCount(self, kmer=None):
+        """getKmerCount(kmer) (TSXHashMap.h:548) or getKmerCount() (:645)."""
+        if kmer is None:
+            return self.stats()["distinct"]
+        return int(self.getKmerCounts(self._as_kmers([kmer]))[0])
+
+    def getKmerCounts(self, kmers):
+        a = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.wk)
+        out = np.zeros(a.shape[0], dtype=np.uint64)
+        _check(self._lib.tsx_hip_get_counts_host(self._h, _p(a), a.shape[0], _p(out)))
+        return out
+
+    def getAllKmers(self):
+        """TSXHashMap::getAllKmers (TSXHashMap.h:660) with counts; order unspecified."""
+        n = self.stats()["distinct"]
+        kmers = np.zeros((max(n, 1), self.wk), dtype=np.uint64)
+        counts = np.zeros(max(n, 1), dtype=np.uint64)
+        got = ctypes.c_size_t(0)
+        _check(self._lib.tsx_hip_dump_host(self._h, _p(kmers), _p(counts), max(n, 1), ctypes.byref(got)))
+        return kmers[:got.value], counts[:got.value]
+
+    def print_stats(self):
+        s = self.stats()
+        import sys
+        print("Used fields: %d" % s["distinct"], file=sys.stderr)
+        print("Available fields: %d" % self.getMaxElements(), file=sys.stderr)
+        print("k=%d l=%d entry limbs=%d storage bits=%d" % (self.k, self.l, self.layout.entry_limbs,
+                                                          self.layout.count_bits), file=sys.stderr)
+        return s
+
+    # --- counting path -----------------------------------------------------
+    def countFastq(self, data):
+        """countKMers (main.cpp:104-218) for one FASTQ text held in host memory."""
+        b = bytes(data)
+        _check(self._lib.tsx_hip_count_fastq_host(self._h, b, len(b)))
+
+    def countFastqDevice(self, dev_ptr, nbytes, stream=None):
+        _check(self._lib.tsx_hip_count_fastq_device(self._h, ctypes.c_void_p(dev_ptr), nbytes,
+                                                    ctypes.c_void_p(stream) if stream else None))
+
+    def clear(self):
+        _check(self._lib.tsx_hip_clear(self._h))
+
+    def sync(self):
+        _check(self._lib.tsx_hip_sync(self._h))
+
+    def stats(self):
+        s = Stats()
+        _check(self._lib.tsx_hip_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    # --- mapping -------------------------------------------------------------
+    def hash_rows(self):
+        out = np.zeros((2 * self.k, self.wk), dtype=np.uint64)
+        _check(self._lib.tsx_hip_hash_rows(self._h, _p(out)))
+        return out
+
+    def hash_apply(self, kmer):
+        a = np.ascontiguousarray(kmer, dtype=np.uint64)
+        out = np.zeros(self.wk, dtype=np.uint64)
+        _check(self._lib.tsx_hip_hash_apply(self._h, _p(a), _p(out)))
+        return out
+
+    def hash_invert(self, key):
+        a = np.ascontiguousarray(key, dtype=np.uint64)
+        out = np.zeros(self.wk, dtype=np.uint64)
+        _check(self._lib.tsx_hip_hash_invert(self._h, _p(a), _p(out)))
+        return out
+
+    def owner(self, kmer, nranks):
+        a = np.ascontiguousarray(kmer, dtype=np.uint64)
+        return int(self._lib.tsx_hip_owner_host(self._h, _p(a), nranks))
+
+    def _as_kmers(self, items):
+        out = np.zeros((len(items), self.wk), dtype=np.uint64)
+        for i, it in enumerate(items):
+            out[i] = encode(it, self.k) if isinstance(it, (str, bytes)) else np.asarray(it, dtype=np.uint64)
+        return out
+
+
+def synth_sizes(seed, first_read, n_reads, k, want_polya=False):
+    """Byte and k-mer totals of tsx_hip_synth_fastq_device without generating."""
+    nb, nk, npa = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _check(lib().tsx_hip_synth_fastq_device(seed, first_read, n_reads, k, None, 0, ctypes.byref(nb),
+                                            ctypes.byref(nk), ctypes.byref(npa) if want_polya else None, 0, None))
+    return int(nb.value), int(nk.value), int(npa.value)
+
+
+def synth_fastq_device(seed, first_read, n_reads, k, dev_ptr, cap, device=0, stream=None):
+    nb, nk = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    _check(lib().tsx_hip_synth_fastq_device(seed, first_read, n_reads, k, ctypes.c_void_p(dev_ptr), cap,
+                                            ctypes.byref(nb), ctypes.byref(nk), None, device,
+                                            ctypes.c_void_p(stream) if stream else None))
+    return int(nb.value), int(nk.value)

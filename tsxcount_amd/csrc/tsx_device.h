@@ -1,0 +1,201 @@
+// tsx_device.h -- device-side table layout and the insert / lookup primitives
+// of the MI355X k-mer counting hash map (gfx950 only, wave64).
+//
+// Slot layout (DESIGN.md "Data layout in HBM"): a slot is W uint64 limbs.
+//   limb 0, bits [0,R)        reprobe count i (>=1 once occupied) -- the low l
+//                             bits of the hashed key are implied by the slot
+//                             position, as in TSXHashMap::makeKey
+//                             (TSXHashMap.h:1056-1072)
+//   limb 0, bits [R,K0)       low func bits of the hashed key (TSXTypes.h:39)
+//   limb 0, bit  K0           LOCK, only when W > 1
+//   limb 0, bits [64-C,64)    in-slot count (the reference's "value"/storage
+//                             bits, TSXHashMap.h:83), wraps modulo 2^C
+//   limbs 1..W-1              remaining func bits
+// A slot is empty iff limb 0 == 0 (TSXHashMap::positionEmpty, TSXHashMap.h:1121).
+// Count wrap-around carries into the secondary array keyed by slot position,
+// which replaces the reference's in-table overflow chain
+// (TSXHashMapPerf.h:699-881): total = count + (carry << C).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsx {
+
+enum StatIdx {
+    ST_KMERS = 0,      // k-mer occurrences handed to insert
+    ST_FAIL = 1,       // occurrences that ran out of reprobes
+    ST_CARRY = 2,      // carries pushed to the secondary array
+    ST_SECFAIL = 3,    // carries that found the secondary array full
+    ST_LOCKTO = 4,     // bounded lock spins that expired
+    ST_SCRATCH = 5,    // reductions (distinct, ...)
+    ST_SCRATCH2 = 6,
+    ST_N = 8
+};
+
+struct TableParams {
+    uint64_t *table;            // slots * W limbs
+    uint64_t *sec_keys;         // secondary array: slot position + 1
+    uint64_t *sec_cnt;          // secondary array: carry count
+    unsigned long long *stats;  // ST_N device counters
+    const uint64_t *lut;        // hash LUT   [groups][1<<g][WK]
+    const uint64_t *ilut;       // inverse    [groups][1<<g][WK]
+    uint64_t slot_mask;         // 2^l - 1
+    uint64_t sec_mask;
+    uint64_t k0mask;            // key bits of limb 0
+    uint64_t lock_bit;          // 0 when W == 1
+    uint64_t top_mask;          // valid bits of the top key limb
+    int k, l, n, wk, W;
+    int R, F, C, K0, cshift;    // cshift = 64 - C
+    int g, groups;              // LUT granularity (4 or 8 bits) and group count
+    uint32_t max_reprobes;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// Bijective GF(2) mapping by table lookup: A*x = XOR over byte/nibble groups of
+// LUT[group][value] (BijectiveKMapping::applyto, BijectiveKMapping.h:202-225,
+// evaluates the same product row by row with AND + popcount).
+template <int WK, typename LutPtr>
+__device__ __forceinline__ void hash_apply(const TableParams &p, LutPtr lut, const uint64_t (&x)[WK],
+                                           uint64_t (&h)[WK]) {
+#pragma unroll
+    for (int t = 0; t < WK; ++t) h[t] = 0;
+    const int g = p.g;
+    const uint32_t gm = (1u << g) - 1u;
+    const int per_limb = 64 / g;
+    for (int grp = 0; grp < p.groups; ++grp) {
+        const int limb = grp / per_limb;
+        const uint32_t v = (uint32_t)(x[limb < WK ? limb : 0] >> ((grp % per_limb) * g)) & gm;
+        const uint64_t *e = (const uint64_t *)(lut + ((size_t)((grp << g) + v)) * WK);
+#pragma unroll
+        for (int t = 0; t < WK; ++t) h[t] ^= e[t];
+    }
+}
+
+// Secondary (count overflow) array: open addressing keyed by slot position.
+__device__ inline void sec_add(const TableParams &p, uint64_t pos, uint64_t carry) {
+    uint64_t slot = mix64(pos + 0x9E3779B97F4A7C15ULL) & p.sec_mask;
+    atomicAdd(&p.stats[ST_CARRY], (unsigned long long)carry);
+    for (int probe = 0; probe < 256; ++probe) {
+        unsigned long long old = atomicCAS((unsigned long long *)&p.sec_keys[slot], 0ULL,
+                                           (unsigned long long)(pos + 1));
+        if (old == 0ULL || old == pos + 1) {
+            atomicAdd((unsigned long long *)&p.sec_cnt[slot], (unsigned long long)carry);
+            return;
+        }
+        slot = (slot + 1) & p.sec_mask;
+    }
+    atomicAdd(&p.stats[ST_SECFAIL], (unsigned long long)carry);
+}
+__device__ inline uint64_t sec_get(const TableParams &p, uint64_t pos) {
+    uint64_t slot = mix64(pos + 0x9E3779B97F4A7C15ULL) & p.sec_mask;
+    for (int probe = 0; probe < 256; ++probe) {
+        uint64_t key = p.sec_keys[slot];
+        if (key == pos + 1) return p.sec_cnt[slot];
+        if (key == 0) return 0;
+        slot = (slot + 1) & p.sec_mask;
+    }
+    return 0;
+}
+
+// Split a hashed key into what a slot stores: e0 = limb-0 key bits without the
+// reprobe count, hi[] = the func bits that spill into limbs 1..W-1.
+template <int WK>
+__device__ __forceinline__ void split_key(const TableParams &p, const uint64_t (&h)[WK], uint64_t &pos0,
+                                          uint64_t &e0, uint64_t (&hi)[4]) {
+    pos0 = h[0] & p.slot_mask;
+    // fr = (h >> l) << R, as WK+1 limbs
+    uint64_t f[WK + 1];
+#pragma unroll
+    for (int t = 0; t < WK; ++t) {
+        uint64_t v = h[t] >> p.l;
+        if (t + 1 < WK) v |= h[t + 1] << (64 - p.l);
+        f[t] = v;
+    }
+    f[WK] = 0;
+    uint64_t fr[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = WK; t >= 0; --t) {
+        uint64_t v = f[t] << p.R;
+        if (t > 0) v |= f[t - 1] >> (64 - p.R);
+        fr[t] = v;
+    }
+    e0 = fr[0] & p.k0mask;
+    // hi = fr >> K0 (1 <= K0 <= 63)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hi[t] = (fr[t] >> p.K0) | (fr[t + 1] << (64 - p.K0));
+}
+
+// addKmer (TSXHashMap.h:182-350, CAS form TSXHashMapCAS.h:268-508) for one
+// hashed key with d occurrences.  One 64-bit CAS claims an empty slot, one
+// atomic add bumps an existing one; probing is the reference's
+// pos = (key + i(i+1)/2) mod 2^l, i = 1,2,... (TSXHashMap.h:759-778,1046-1054).
+template <int WK>
+__device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK], uint64_t d) {
+    uint64_t pos0, e0, hi[4];
+    split_key<WK>(p, h, pos0, e0, hi);
+    const uint64_t dlow = d << p.cshift;
+    const int W = p.W;
+    uint32_t i = 1;
+    uint32_t spins = 0;
+    while (i <= p.max_reprobes) {
+        const uint64_t pos = (pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.slot_mask;
+        unsigned long long *e = (unsigned long long *)(p.table + pos * (uint64_t)W);
+        const uint64_t key0 = e0 | i;
+        const unsigned long long old = atomicCAS(e, 0ULL, (unsigned long long)(key0 | p.lock_bit | dlow));
+        if (old == 0ULL) {
+            if (W > 1) {
+                for (int t = 1; t < W; ++t) atomicExch(e + t, (unsigned long long)hi[t - 1]);
+                // the limb stores must have landed before the slot is unlocked
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                atomicAnd(e, ~(unsigned long long)p.lock_bit);
+            }
+            const uint64_t carry = d >> p.C;
+            if (carry) sec_add(p, pos, carry);
+            return true;
+        }
+        if ((old & p.k0mask) != key0) { ++i; continue; }
+        if (W > 1) {
+            if (old & p.lock_bit) {  // claimed, limbs not published yet: look again
+                if (++spins > (1u << 22)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); ++i; spins = 0; }
+                continue;
+            }
+            bool same = true;
+            for (int t = 1; t < W; ++t) same &= (atomicOr(e + t, 0ULL) == hi[t - 1]);
+            if (!same) { ++i; continue; }
+        }
+        const unsigned long long prev = atomicAdd(e, (unsigned long long)dlow);
+        const uint64_t carry = ((prev >> p.cshift) + d) >> p.C;
+        if (carry) sec_add(p, pos, carry);
+        return true;
+    }
+    atomicAdd(&p.stats[ST_FAIL], (unsigned long long)d);
+    return false;
+}
+
+// getKmerCount(kmer) (TSXHashMap.h:548-638).  Plain loads: runs in its own
+// launch after every insert kernel has finished.
+template <int WK>
+__device__ inline uint64_t lookup_key(const TableParams &p, const uint64_t (&h)[WK]) {
+    uint64_t pos0, e0, hi[4];
+    split_key<WK>(p, h, pos0, e0, hi);
+    const int W = p.W;
+    for (uint32_t i = 1; i <= p.max_reprobes; ++i) {
+        const uint64_t pos = (pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.slot_mask;
+        const uint64_t *e = p.table + pos * (uint64_t)W;
+        const uint64_t v = e[0];
+        if (v == 0) return 0;  // "why would the insertion skip an empty place?" TSXHashMap.h:622-626
+        if ((v & p.k0mask) != (e0 | i)) continue;
+        bool same = true;
+        for (int t = 1; t < W; ++t) same &= (e[t] == hi[t - 1]);
+        if (!same) continue;
+        return (v >> p.cshift) + (sec_get(p, pos) << p.C);
+    }
+    return 0;
+}
+
+}  // namespace tsx

@@ -1,0 +1,432 @@
+// tsx_kernels.h -- the HIP kernels of the counting path (gfx950, wave64).
+//
+//   line_count_kernel   FASTQ pass 1: non-empty line terminators per tile
+//   line_scan_kernel    FASTQ pass 2: exclusive scan -> line index at tile start
+//   count_fastq_kernel  FASTQ pass 3: scan + 2-bit encode + hash + dedup + insert
+//   add_kmers_kernel    addKmer for a batch of encoded k-mers
+//   get_counts_kernel   getKmerCount(kmer) for a batch
+//   occupied_kernel     getKmerCount() (occupied slots)
+//   dump_kernel         getAllKmers + counts, optionally grouped by owner rank
+//   synth_fill_kernel   synthetic FASTQ text (generateFakeSequences.py shape)
+#pragma once
+#include "tsx_device.h"
+
+namespace tsx {
+
+constexpr int NT = 256;          // threads per workgroup (4 waves)
+constexpr int TILE = 4096;       // FASTQ bytes (k-mer start positions) per tile
+constexpr int HALO = 128;        // bytes past the tile a window may reach (k <= 128)
+constexpr int BATCH = 2048;      // start positions per dedup round (8 per thread)
+constexpr int PER_THREAD = BATCH / NT;
+constexpr int DSLOTS = 4096;     // LDS dedup slots per round
+constexpr int DPROBES = 8;
+
+__device__ __forceinline__ bool is_nl(uint32_t b) { return b == (uint32_t)'\n'; }
+// SequenceUtils.h:98-125: A=0 C=1 G=2 T=3; same formula for every other byte
+__device__ __forceinline__ uint32_t base_code(uint32_t b) { return ((b >> 1) ^ (b >> 2)) & 3u; }
+
+// 16 bytes -> 16 newline flags, 16 line-end flags (newline that closes a
+// non-empty line, FastXReader.h:365-370 drops empty lines), 32 code bits.
+__device__ __forceinline__ void classify16(const uint4 v, bool prev_nl, uint32_t &nl16, uint32_t &le16,
+                                           uint32_t &code32) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    nl16 = 0; code32 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t b = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        nl16 |= (is_nl(b) ? 1u : 0u) << i;
+        code32 |= base_code(b) << (2 * i);
+    }
+    const uint32_t prev = (nl16 << 1) | (prev_nl ? 1u : 0u);  // bit i = byte i-1 is a newline
+    le16 = nl16 & ~prev & 0xFFFFu;
+}
+
+// Loads 16 bytes at byte offset off (multiple of 16) of a text of n bytes;
+// bytes at or past n read as '\n' (the last line may lack its terminator).
+__device__ __forceinline__ uint4 load16(const uint8_t *buf, uint64_t off, uint64_t n) {
+    if (off + 16 <= n) return *reinterpret_cast<const uint4 *>(buf + off);
+    uint32_t w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    for (int i = 0; i < 16; ++i)
+        if (off + i < n) {
+            w[i >> 2] &= ~(0xFFu << ((i & 3) * 8));
+            w[i >> 2] |= (uint32_t)buf[off + i] << ((i & 3) * 8);
+        }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// Is the byte before offset off a newline?  Offset 0 counts as a line start
+// unless the caller says a previous piece ended mid-line.
+__device__ __forceinline__ bool prev_is_nl(const uint8_t *buf, uint64_t off, uint64_t n, int head_open) {
+    if (off == 0) return !head_open;
+    if (off - 1 >= n) return true;
+    return buf[off - 1] == (uint8_t)'\n';
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Pass 1: tile_cnt[t] = number of non-empty line terminators in tile t.
+__global__ __launch_bounds__(NT) void line_count_kernel(const uint8_t *buf, uint64_t n, uint64_t own_end,
+                                                        int head_open, uint32_t *tile_cnt, uint64_t ntiles) {
+    __shared__ uint32_t s_w[NT / 64];
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t off = tile * TILE + (uint64_t)threadIdx.x * 16;
+        uint32_t nl, le, code;
+        classify16(load16(buf, off, n), prev_is_nl(buf, off, n, head_open), nl, le, code);
+        // terminators at or past own_end belong to the next piece
+        if (off + 16 > own_end) le &= (off >= own_end) ? 0u : ((1u << (own_end - off)) - 1u);
+        uint32_t c = __popc(le);
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_cnt[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+}
+
+// Pass 2: one workgroup turns tile_cnt into the line index at each tile start
+// (in place, exclusive), starting from *carry (lines seen in earlier pieces)
+// and leaving the running total there.
+__global__ __launch_bounds__(1024) void line_scan_kernel(uint32_t *tile_cnt, uint64_t ntiles, uint32_t *carry) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_base;
+    if (threadIdx.x == 0) s_base = *carry;
+    __syncthreads();
+    for (uint64_t start = 0; start < ntiles; start += 1024) {
+        const uint64_t i = start + threadIdx.x;
+        const uint32_t v = (i < ntiles) ? tile_cnt[i] : 0;
+        const uint32_t inc = wave_incl_scan(v);
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_w[w];
+        const uint32_t base = s_base;
+        if (i < ntiles) tile_cnt[i] = base + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = base + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *carry = s_base;
+}
+
+// Extract the k-mer that starts at byte position p of the tile from the packed
+// 2-bit code array in LDS (UBigInt layout: base i in bits 2i,2i+1).
+template <int WK>
+__device__ __forceinline__ void extract_kmer(const uint64_t *s_codes, uint32_t p, uint64_t top_mask,
+                                             uint64_t (&x)[WK]) {
+    const uint32_t w = p >> 5, o = (2 * p) & 63;
+#pragma unroll
+    for (int t = 0; t < WK; ++t) {
+        uint64_t v = s_codes[w + t] >> o;
+        if (o) v |= s_codes[w + t + 1] << (64 - o);
+        x[t] = v;
+    }
+    x[WK - 1] &= top_mask;
+}
+template <int WK>
+__device__ __forceinline__ bool kmer_eq(const uint64_t (&a)[WK], const uint64_t (&b)[WK]) {
+    bool e = true;
+#pragma unroll
+    for (int t = 0; t < WK; ++t) e &= (a[t] == b[t]);
+    return e;
+}
+
+// Pass 3: the hot path.  Per tile of TILE bytes:
+//   1. 16 B/lane coalesced loads; classify into newline / line-end bit masks
+//      and a packed 2-bit code array in LDS (no byte ever re-read from HBM
+//      except the k-1 byte halo);
+//   2. workgroup prefix sum of line ends -> line index of every byte, so that
+//      "second line of a 4-line record" (FastXReader.h:71-77) is a bit test;
+//   3. per start position: window test against the newline mask
+//      (createKMers, testExecution.h:15-36), funnel-shift extract of the 2k
+//      bits (fromSequence), run-length merge of equal neighbours across the
+//      wave (shuffle + ballot), LUT hash, claim-or-accumulate in an LDS dedup
+//      table;
+//   4. after a barrier the claimant of each dedup slot issues ONE global
+//      insert carrying the slot's total.
+template <int WK>
+__global__ __launch_bounds__(NT) void count_fastq_kernel(TableParams p, const uint8_t *buf, uint64_t n,
+                                                         uint64_t own_end, int head_open,
+                                                         const uint32_t *tile_line, uint64_t ntiles) {
+    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
+    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
+    __shared__ uint64_t s_le[TILE / 64];
+    __shared__ uint8_t s_lb[TILE / 16];
+    __shared__ uint32_t s_wsum[NT / 64];
+    __shared__ uint32_t s_dpos[DSLOTS];
+    __shared__ uint32_t s_dcnt[DSLOTS];
+    extern __shared__ uint64_t s_lut[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int lut_words = p.groups * (1 << p.g) * WK;
+    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
+    for (int i = tid; i < DSLOTS; i += NT) { s_dpos[i] = 0; s_dcnt[i] = 0; }
+    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
+    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
+    unsigned long long added = 0;
+    const uint32_t k = (uint32_t)p.k;
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * TILE;
+        __syncthreads();  // previous tile's LDS fully consumed
+        {
+            const uint64_t off = base + (uint64_t)tid * 16;
+            uint32_t nl, le, code;
+            classify16(load16(buf, off, n), prev_is_nl(buf, off, n, head_open), nl, le, code);
+            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
+            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
+            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
+            if (tid < HALO / 16) {
+                const uint64_t hoff = base + TILE + (uint64_t)tid * 16;
+                uint32_t hnl, hle, hcode;
+                classify16(load16(buf, hoff, n), false, hnl, hle, hcode);
+                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
+                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
+            }
+            const uint32_t c = __popc(le);
+            const uint32_t inc = wave_incl_scan(c);
+            if (lane == 63) s_wsum[tid >> 6] = inc;
+            __syncthreads();
+            uint32_t woff = tile_line[tile];
+            for (int w = 0; w < (tid >> 6); ++w) woff += s_wsum[w];
+            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        __syncthreads();
+
+        for (int round = 0; round < TILE / BATCH; ++round) {
+            uint64_t hk[PER_THREAD][WK];
+            int slot_of[PER_THREAD];      // >=0: claimed LDS slot, -1: nothing to insert, -2: direct
+            uint32_t direct_cnt[PER_THREAD];
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; ++j) {
+                const uint32_t pp = (uint32_t)(round * BATCH + j * NT + tid);
+                const uint64_t gpos = base + pp;
+                // line index of this byte: group base + line ends before it in the group
+                const uint32_t grp = pp >> 4;
+                const uint32_t le_before = reinterpret_cast<const uint16_t *>(s_le)[grp] & ((1u << (pp & 15)) - 1u);
+                const uint32_t line = (uint32_t)s_lb[grp] + __popc(le_before);
+                // no newline inside [pp, pp+k)
+                const uint32_t w = pp >> 6, o = pp & 63;
+                uint64_t m0 = s_nl[w] >> o, m1 = s_nl[w + 1] >> o;
+                if (o) { m0 |= s_nl[w + 1] << (64 - o); m1 |= s_nl[w + 2] << (64 - o); }
+                const uint64_t need0 = (k >= 64) ? ~0ULL : ((1ULL << k) - 1ULL);
+                const uint64_t need1 = (k > 64) ? ((k >= 128) ? ~0ULL : ((1ULL << (k - 64)) - 1ULL)) : 0ULL;
+                const bool valid = ((line & 3u) == 1u) && ((m0 & need0) == 0) && ((m1 & need1) == 0) &&
+                                   (gpos + k <= n) && (gpos < own_end);
+                uint64_t x[WK];
+                extract_kmer<WK>(s_codes, pp, p.top_mask, x);
+                // run-length merge across the wave: lanes hold consecutive positions
+                uint64_t xp[WK];
+#pragma unroll
+                for (int t = 0; t < WK; ++t) xp[t] = __shfl_up((unsigned long long)x[t], 1, 64);
+                const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
+                const bool leader = valid && (lane == 0 || !prev_valid || !kmer_eq<WK>(x, xp));
+                const unsigned long long bnd = __ballot(leader || !valid);
+                const unsigned long long above = (lane == 63) ? 0ULL : (bnd >> (lane + 1));
+                const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)(63 - lane)) + 1u;
+                added += valid ? 1ULL : 0ULL;
+                slot_of[j] = -1; direct_cnt[j] = 0;
+                if (leader) {
+                    hash_apply<WK>(p, (const uint64_t *)s_lut, x, hk[j]);
+                    uint32_t slot = (uint32_t)(mix64(hk[j][0] ^ (WK > 1 ? hk[j][WK - 1] : 0)) >> 40) & (DSLOTS - 1);
+                    slot_of[j] = -2; direct_cnt[j] = runlen;
+                    for (int pr = 0; pr < DPROBES; ++pr) {
+                        const uint32_t old = atomicCAS(&s_dpos[slot], 0u, pp + 1u);
+                        if (old == 0u) {
+                            atomicAdd(&s_dcnt[slot], runlen);
+                            slot_of[j] = (int)slot;
+                            break;
+                        }
+                        uint64_t y[WK];
+                        extract_kmer<WK>(s_codes, old - 1u, p.top_mask, y);
+                        if (kmer_eq<WK>(x, y)) {
+                            atomicAdd(&s_dcnt[slot], runlen);
+                            slot_of[j] = -1;
+                            break;
+                        }
+                        slot = (slot + 1) & (DSLOTS - 1);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; ++j) {
+                if (slot_of[j] == -1) continue;
+                uint64_t d = direct_cnt[j];
+                if (slot_of[j] >= 0) {
+                    d = s_dcnt[slot_of[j]];
+                    s_dcnt[slot_of[j]] = 0;
+                    s_dpos[slot_of[j]] = 0;
+                }
+                insert_key<WK>(p, hk[j], d);
+            }
+            __syncthreads();
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
+}
+
+// addKmer for encoded k-mers already on the device (API batches, merge inserts).
+template <int WK>
+__global__ __launch_bounds__(NT) void add_kmers_kernel(TableParams p, const uint64_t *kmers,
+                                                       const uint64_t *counts, uint64_t n) {
+    unsigned long long added = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) {
+        uint64_t x[WK], h[WK];
+#pragma unroll
+        for (int t = 0; t < WK; ++t) x[t] = kmers[i * WK + t];
+        x[WK - 1] &= p.top_mask;
+        const uint64_t d = counts ? counts[i] : 1ULL;
+        if (d == 0) continue;
+        hash_apply<WK>(p, p.lut, x, h);
+        insert_key<WK>(p, h, d);
+        added += d;
+    }
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if ((threadIdx.x & 63) == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
+}
+
+template <int WK>
+__global__ __launch_bounds__(NT) void get_counts_kernel(TableParams p, const uint64_t *kmers, uint64_t n,
+                                                        uint64_t *out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) {
+        uint64_t x[WK], h[WK];
+#pragma unroll
+        for (int t = 0; t < WK; ++t) x[t] = kmers[i * WK + t];
+        x[WK - 1] &= p.top_mask;
+        hash_apply<WK>(p, p.lut, x, h);
+        out[i] = lookup_key<WK>(p, h);
+    }
+}
+
+// getKmerCount(): occupied primary slots -> stats[ST_SCRATCH]; occupied
+// secondary slots -> stats[ST_SCRATCH2].
+__global__ __launch_bounds__(NT) void occupied_kernel(TableParams p) {
+    unsigned long long c = 0, c2 = 0;
+    const uint64_t slots = p.slot_mask + 1, sslots = p.sec_mask + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * NT)
+        c += (p.table[i * (uint64_t)p.W] != 0) ? 1ULL : 0ULL;
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < sslots; i += (uint64_t)gridDim.x * NT)
+        c2 += (p.sec_keys[i] != 0) ? 1ULL : 0ULL;
+    for (int d = 32; d > 0; d >>= 1) { c += __shfl_down(c, d, 64); c2 += __shfl_down(c2, d, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (c) atomicAdd(&p.stats[ST_SCRATCH], c);
+        if (c2) atomicAdd(&p.stats[ST_SCRATCH2], c2);
+    }
+}
+
+// Rebuild the k-mer stored in slot `pos` (TSXHashMap::getAllKmers,
+// TSXHashMap.h:660-722): hashed key = func bits | (pos - i(i+1)/2 mod 2^l),
+// then the inverse mapping.
+template <int WK>
+__device__ __forceinline__ void slot_to_kmer(const TableParams &p, uint64_t pos, uint64_t (&x)[WK],
+                                             uint64_t &count) {
+    const uint64_t *e = p.table + pos * (uint64_t)p.W;
+    const uint64_t v = e[0];
+    const uint32_t i = (uint32_t)(v & ((1ULL << p.R) - 1ULL));
+    const uint64_t pos0 = (pos - (((uint64_t)i * (i + 1)) >> 1)) & p.slot_mask;
+    // fr = key bits above the reprobe field: limb-0 part, then limbs 1..W-1 placed at bit K0
+    uint64_t fr[6] = {0, 0, 0, 0, 0, 0};
+    fr[0] = v & p.k0mask & ~((1ULL << p.R) - 1ULL);
+    for (int t = 1; t < p.W; ++t) {
+        const uint64_t hv = e[t];
+        fr[t - 1] |= hv << p.K0;
+        fr[t] |= hv >> (64 - p.K0);
+    }
+    // func = fr >> R ; h = (func << l) | pos0
+    uint64_t h[WK];
+    uint64_t func[6];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) func[t] = (fr[t] >> p.R) | (fr[t + 1] << (64 - p.R));
+    func[5] = 0;
+#pragma unroll
+    for (int t = 0; t < WK; ++t) {
+        uint64_t hv = func[t] << p.l;
+        if (t > 0) hv |= func[t - 1] >> (64 - p.l);
+        h[t] = hv;
+    }
+    h[0] |= pos0;
+    h[WK - 1] &= p.top_mask;
+    hash_apply<WK>(p, p.ilut, h, x);
+    count = (v >> p.cshift) + (sec_get(p, pos) << p.C);
+}
+
+__device__ __forceinline__ int owner_of(const uint64_t *x, int wk, int nranks) {
+    uint64_t z = 0x243F6A8885A308D3ULL;
+    for (int t = 0; t < wk; ++t) z = mix64(z ^ x[t]);
+    return (int)((z >> 32) * (uint64_t)nranks >> 32);
+}
+
+// mode 0: count occupied slots per owner into seg[0..nranks)
+// mode 1: write k-mer + count at seg_cursor[owner]++ (cursors preset to segment starts)
+template <int WK>
+__global__ __launch_bounds__(NT) void dump_kernel(TableParams p, int nranks, int mode, uint64_t *kmers_out,
+                                                  uint64_t *counts_out, uint64_t cap,
+                                                  unsigned long long *seg) {
+    const uint64_t slots = p.slot_mask + 1;
+    for (uint64_t pos = (uint64_t)blockIdx.x * NT + threadIdx.x; pos < slots; pos += (uint64_t)gridDim.x * NT) {
+        if (p.table[pos * (uint64_t)p.W] == 0) continue;
+        uint64_t x[WK], c;
+        slot_to_kmer<WK>(p, pos, x, c);
+        const int own = (nranks > 1) ? owner_of(x, WK, nranks) : 0;
+        if (mode == 0) {
+            atomicAdd(&seg[own], 1ULL);
+        } else {
+            const unsigned long long at = atomicAdd(&seg[own], 1ULL);
+            if (at < cap) {
+#pragma unroll
+                for (int t = 0; t < WK; ++t) kmers_out[at * WK + t] = x[t];
+                counts_out[at] = c;
+            }
+        }
+    }
+}
+
+// Synthetic FASTQ: one workgroup per read, record layout
+// "@seq<i>\n" bases "\n+\n" qualities "\n"  (generateFakeSequences.py:17-20).
+__device__ __host__ inline uint64_t synth_mix(uint64_t seed, uint64_t i, uint64_t c) {
+    uint64_t z = seed + i * 0x9E3779B97F4A7C15ULL + c * 0xD1B54A32D192ED03ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(NT) void synth_fill_kernel(uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                                        const uint64_t *offsets, uint8_t *out) {
+    for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint64_t id = first_read + r;
+        const uint32_t nrand = 500u + (uint32_t)(synth_mix(seed, id, 0) % 501u);
+        const uint32_t na = 100u + (uint32_t)(synth_mix(seed, id, 1) % 201u);
+        const uint32_t L = nrand + na;
+        uint8_t *o = out + offsets[r];
+        // header
+        char digits[24]; int nd = 0; uint64_t v = id;
+        do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+        const uint32_t hl = 4u + (uint32_t)nd + 1u;
+        if (threadIdx.x == 0) {
+            o[0] = '@'; o[1] = 's'; o[2] = 'e'; o[3] = 'q';
+            for (int d = 0; d < nd; ++d) o[4 + d] = (uint8_t)digits[nd - 1 - d];
+            o[4 + nd] = '\n';
+        }
+        uint8_t *seq = o + hl;
+        for (uint32_t j = threadIdx.x; j < L; j += NT) {
+            uint8_t ch = 'A';
+            if (j < nrand) {
+                const uint64_t w = synth_mix(seed, id, 2 + (j >> 5));
+                ch = (uint8_t)"ACGT"[(w >> (2 * (j & 31))) & 3];
+            }
+            seq[j] = ch;
+            seq[L + 3 + j] = '&';
+        }
+        if (threadIdx.x == 0) { seq[L] = '\n'; seq[L + 1] = '+'; seq[L + 2] = '\n'; seq[2 * L + 3] = '\n'; }
+    }
+}
+
+}  // namespace tsx

@@ -1,0 +1,620 @@
+// tsxcount_hip.hip -- C ABI (include/tsxcount_hip.h) over the HIP kernels.
+// Host side only: layout derivation, the bijective mapping and its lookup
+// tables, launches, staging copies.  No CPU counting path exists here.
+#include "../../include/tsxcount_hip.h"
+#include "tsx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tsx;
+
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);            \
+            return (_e == hipErrorOutOfMemory) ? TSX_HIP_ENOMEM : TSX_HIP_EHIP;          \
+        }                                                                                \
+    } while (0)
+
+struct tsx_hip_map {
+    TableParams p{};
+    tsx_hip_layout lay{};
+    int device = 0;
+    uint64_t seed = 0;
+    hipStream_t stream = nullptr;
+    // bijective mapping, host copy: rows[i] yields output bit n-1-i
+    std::vector<uint64_t> rows, irows;   // n x wk
+    std::vector<uint64_t> lut, ilut;     // [groups][1<<g][wk]
+    uint64_t *d_lut = nullptr, *d_ilut = nullptr;
+    // FASTQ scratch
+    uint32_t *d_tile = nullptr; uint64_t tile_cap = 0;
+    uint32_t *d_carry = nullptr;
+    unsigned long long *d_seg = nullptr;  // 64 owner counters / cursors
+    // host staging
+    uint8_t *h_stage[2] = {nullptr, nullptr};
+    uint8_t *d_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    int cus = 256;
+};
+
+static const size_t STAGE_PIECE = (size_t)64 << 20;  // bytes of FASTQ per host piece
+static const size_t STAGE_PAD = 256;
+
+extern "C" int tsx_hip_key_limbs(int k) { return (k < 1 || k > 127) ? TSX_HIP_EINVAL : (2 * k + 63) / 64; }
+
+extern "C" const char *tsx_hip_strerror(int code) {
+    switch (code) {
+        case TSX_HIP_OK: return "ok";
+        case TSX_HIP_EINVAL: return "Invalid lengths for hashmap size and value of k";
+        case TSX_HIP_ENODEVICE: return "no HIP device";
+        case TSX_HIP_ENOMEM: return "device memory exhausted";
+        case TSX_HIP_EHIP: return "HIP runtime error";
+        case TSX_HIP_EFULL: return "Could not insert kmer: table full";
+        case TSX_HIP_EOVERFLOW: return "count overflow array full";
+        case TSX_HIP_ERANGE: return "output buffer too small";
+    }
+    return "unknown";
+}
+extern "C" const char *tsx_hip_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int tsx_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static inline unsigned code_of(unsigned char b) { return ((b >> 1) ^ (b >> 2)) & 3u; }
+
+extern "C" int tsx_hip_encode(const char *seq, int k, uint64_t *out) {
+    if (!seq || !out || k < 1 || k > 127) return TSX_HIP_EINVAL;
+    const int wk = (2 * k + 63) / 64;
+    memset(out, 0, (size_t)wk * 8);
+    for (int i = 0; i < k; ++i) out[(2 * i) >> 6] |= (uint64_t)code_of((unsigned char)seq[i]) << ((2 * i) & 63);
+    return TSX_HIP_OK;
+}
+extern "C" int tsx_hip_decode(const uint64_t *limbs, int k, char *out) {
+    if (!limbs || !out || k < 1 || k > 127) return TSX_HIP_EINVAL;
+    for (int i = 0; i < k; ++i) out[i] = "ACGT"[(limbs[(2 * i) >> 6] >> ((2 * i) & 63)) & 3];
+    out[k] = 0;
+    return TSX_HIP_OK;
+}
+
+// ---- bijective GF(2) mapping ------------------------------------------------
+// Same family as BijectiveKMapping::getRandomMatrix (BijectiveKMapping.h:284-303):
+// unit upper triangular, random above the diagonal.  Row i carries bit
+// (n-1-j) = M[i][j] (matrixToRows, :227-256) and yields output bit n-1-i
+// (applyto, :202-225).  Seeded splitmix64 replaces srand(time(NULL)).
+static uint64_t splitmix_next(uint64_t &st) {
+    uint64_t z = (st += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline int rbit(const uint64_t *r, int i) { return (int)((r[i >> 6] >> (i & 63)) & 1); }
+static inline void rset(uint64_t *r, int i) { r[i >> 6] |= 1ULL << (i & 63); }
+
+static void make_mapping(tsx_hip_map *m) {
+    const int n = m->p.n, wk = m->p.wk;
+    m->rows.assign((size_t)n * wk, 0);
+    m->irows.assign((size_t)n * wk, 0);
+    uint64_t st = m->seed, word = 0; int have = 0;
+    for (int i = 0; i < n; ++i) {
+        uint64_t *row = &m->rows[(size_t)i * wk];
+        rset(row, n - 1 - i);
+        for (int j = i + 1; j < n; ++j) {
+            if (!have) { word = splitmix_next(st); have = 64; }
+            if (word & 1) rset(row, n - 1 - j);
+            word >>= 1; --have;
+        }
+    }
+    // y_p = x_p ^ sum_{q<p} a[p][q] x_q  =>  x_p = y_p ^ sum_{q<p} a[p][q] x_q(y)
+    std::vector<uint64_t> xform((size_t)n * wk, 0);
+    for (int pbit = 0; pbit < n; ++pbit) {
+        const uint64_t *row = &m->rows[(size_t)(n - 1 - pbit) * wk];
+        uint64_t *acc = &xform[(size_t)pbit * wk];
+        rset(acc, pbit);
+        for (int q = 0; q < pbit; ++q)
+            if (rbit(row, q))
+                for (int t = 0; t < wk; ++t) acc[t] ^= xform[(size_t)q * wk + t];
+    }
+    for (int pbit = 0; pbit < n; ++pbit)
+        memcpy(&m->irows[(size_t)(n - 1 - pbit) * wk], &xform[(size_t)pbit * wk], (size_t)wk * 8);
+}
+
+static void apply_rows(const tsx_hip_map *m, const std::vector<uint64_t> &rows, const uint64_t *x, uint64_t *out) {
+    const int n = m->p.n, wk = m->p.wk;
+    memset(out, 0, (size_t)wk * 8);
+    for (int i = 0; i < n; ++i) {
+        uint64_t acc = 0;
+        for (int t = 0; t < wk; ++t) acc ^= rows[(size_t)i * wk + t] & x[t];
+        if (__builtin_parityll(acc)) rset(out, n - 1 - i);
+    }
+}
+
+// LUT[group][v] = A * (v << (g*group)): the mapping is linear, so A*x is the
+// XOR of one table entry per g-bit group of x.
+static void make_lut(const tsx_hip_map *m, const std::vector<uint64_t> &rows, std::vector<uint64_t> &lut) {
+    const int wk = m->p.wk, g = m->p.g, groups = m->p.groups;
+    lut.assign((size_t)groups * (1u << g) * wk, 0);
+    std::vector<uint64_t> x(wk), y(wk);
+    for (int grp = 0; grp < groups; ++grp)
+        for (unsigned v = 0; v < (1u << g); ++v) {
+            std::fill(x.begin(), x.end(), 0);
+            const int bit = grp * g;
+            x[bit >> 6] = (uint64_t)v << (bit & 63);
+            x[wk - 1] &= m->p.top_mask;
+            apply_rows(m, rows, x.data(), y.data());
+            memcpy(&lut[((size_t)grp * (1u << g) + v) * wk], y.data(), (size_t)wk * 8);
+        }
+}
+
+// ---- layout -------------------------------------------------------------------
+static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l) {
+    if (k < 1 || k > 127 || l < 4 || l > 36 || s < 0 || s > 32) return TSX_HIP_EINVAL;
+    if (2 * k <= l) return TSX_HIP_EINVAL;  // TSXHashMap.h:91-94
+    TableParams &p = m->p;
+    p.k = k; p.l = l; p.n = 2 * k; p.wk = (2 * k + 63) / 64;
+    p.R = std::min(l, 8);
+    p.F = 2 * k - l;
+    const int KB = p.R + p.F;
+    int W, C;
+    if (s == 0) {
+        W = (KB + 5 + 63) / 64;
+        C = std::min(32, 64 * W - KB - (W > 1 ? 1 : 0));
+    } else {
+        C = s;
+        W = (KB + C + 63) / 64;
+        if (W > 1) W = (KB + C + 1 + 63) / 64;
+    }
+    const int lock = (W > 1) ? 1 : 0;
+    p.K0 = 64 - C - lock;
+    if (W > 4 || p.K0 < p.R || p.K0 > 63) return TSX_HIP_EINVAL;
+    // all spilled func bits must fit limbs 1..W-1
+    if (KB - p.K0 > 64 * (W - 1)) return TSX_HIP_EINVAL;
+    p.W = W; p.C = C; p.cshift = 64 - C;
+    p.k0mask = (p.K0 >= 64) ? ~0ULL : ((1ULL << p.K0) - 1ULL);
+    p.lock_bit = lock ? (1ULL << p.K0) : 0ULL;
+    p.slot_mask = (1ULL << l) - 1ULL;
+    const uint64_t maxr = (1ULL << p.R) - 1ULL;
+    p.max_reprobes = (uint32_t)std::min<uint64_t>(maxr, p.slot_mask);
+    p.top_mask = (p.n & 63) ? ((1ULL << (p.n & 63)) - 1ULL) : ~0ULL;
+    // LUT granularity: bytes when the table stays <= 32 KiB of LDS, nibbles otherwise
+    const size_t lut8 = (size_t)((p.n + 7) / 8) * 256 * p.wk * 8;
+    p.g = (lut8 <= (32u << 10)) ? 8 : 4;
+    p.groups = (p.n + p.g - 1) / p.g;
+    int ol = overflow_l ? overflow_l : std::max(10, l - 4);
+    if (ol < 4 || ol > 34) return TSX_HIP_EINVAL;
+    p.sec_mask = (1ULL << ol) - 1ULL;
+    tsx_hip_layout &L = m->lay;
+    L.k = k; L.l = l; L.key_limbs = p.wk; L.entry_limbs = W; L.func_bits = p.F; L.reprobe_bits = p.R;
+    L.count_bits = C; L.overflow_l = ol; L.max_reprobes = p.max_reprobes; L.slots = 1ULL << l;
+    L.table_bytes = L.slots * (uint64_t)W * 8ULL;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
+                              uint64_t hash_seed, int device) {
+    if (!out) return TSX_HIP_EINVAL;
+    *out = nullptr;
+    tsx_hip_map *m = new tsx_hip_map();
+    int rc = derive_layout(m, k, l, storagebits, overflow_l);
+    if (rc != TSX_HIP_OK) { delete m; return rc; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        delete m;
+        g_last_error = "no HIP device (the HIP path has no CPU fallback)";
+        return TSX_HIP_ENODEVICE;
+    }
+    m->device = device; m->seed = hash_seed;
+    auto fail = [&](int code) { tsx_hip_destroy(m); return code; };
+#define HIP_TRY_C(expr)                                                         \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);   \
+            return fail(_e == hipErrorOutOfMemory ? TSX_HIP_ENOMEM : TSX_HIP_EHIP); \
+        }                                                                       \
+    } while (0)
+    HIP_TRY_C(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY_C(hipGetDeviceProperties(&prop, device));
+    m->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY_C(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    TableParams &p = m->p;
+    HIP_TRY_C(hipMalloc((void **)&p.table, m->lay.table_bytes));
+    HIP_TRY_C(hipMalloc((void **)&p.sec_keys, (p.sec_mask + 1) * 8));
+    HIP_TRY_C(hipMalloc((void **)&p.sec_cnt, (p.sec_mask + 1) * 8));
+    HIP_TRY_C(hipMalloc((void **)&p.stats, ST_N * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc((void **)&m->d_carry, 64));
+    HIP_TRY_C(hipMalloc((void **)&m->d_seg, 64 * sizeof(unsigned long long)));
+    make_mapping(m);
+    make_lut(m, m->rows, m->lut);
+    make_lut(m, m->irows, m->ilut);
+    HIP_TRY_C(hipMalloc((void **)&m->d_lut, m->lut.size() * 8));
+    HIP_TRY_C(hipMalloc((void **)&m->d_ilut, m->ilut.size() * 8));
+    HIP_TRY_C(hipMemcpy(m->d_lut, m->lut.data(), m->lut.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(m->d_ilut, m->ilut.data(), m->ilut.size() * 8, hipMemcpyHostToDevice));
+    p.lut = m->d_lut; p.ilut = m->d_ilut;
+    rc = tsx_hip_clear(m);
+    if (rc != TSX_HIP_OK) return fail(rc);
+    *out = m;
+    return TSX_HIP_OK;
+#undef HIP_TRY_C
+}
+
+extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
+    (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut);
+    (void)hipFree(m->d_tile); (void)hipFree(m->d_carry); (void)hipFree(m->d_seg);
+    for (int i = 0; i < 2; ++i) {
+        if (m->h_stage[i]) (void)hipHostFree(m->h_stage[i]);
+        if (m->d_stage[i]) (void)hipFree(m->d_stage[i]);
+        if (m->stage_done[i]) (void)hipEventDestroy(m->stage_done[i]);
+    }
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+extern "C" int tsx_hip_get_layout(const tsx_hip_map *m, tsx_hip_layout *out) {
+    if (!m || !out) return TSX_HIP_EINVAL;
+    *out = m->lay;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_clear(tsx_hip_map *m) {
+    if (!m) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemsetAsync(m->p.table, 0, m->lay.table_bytes, m->stream));
+    HIP_TRY(hipMemsetAsync(m->p.sec_keys, 0, (m->p.sec_mask + 1) * 8, m->stream));
+    HIP_TRY(hipMemsetAsync(m->p.sec_cnt, 0, (m->p.sec_mask + 1) * 8, m->stream));
+    HIP_TRY(hipMemsetAsync(m->p.stats, 0, ST_N * sizeof(unsigned long long), m->stream));
+    return TSX_HIP_OK;
+}
+
+static int read_stats(tsx_hip_map *m, unsigned long long *st) {
+    HIP_TRY(hipMemcpyAsync(st, m->p.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_sync(tsx_hip_map *m) {
+    if (!m) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    unsigned long long st[ST_N];
+    int rc = read_stats(m, st);
+    if (rc != TSX_HIP_OK) return rc;
+    if (st[ST_FAIL]) return TSX_HIP_EFULL;
+    if (st[ST_SECFAIL]) return TSX_HIP_EOVERFLOW;
+    return TSX_HIP_OK;
+}
+
+static inline hipStream_t pick_stream(tsx_hip_map *m, void *stream) { return stream ? (hipStream_t)stream : m->stream; }
+static inline int grid_for(const tsx_hip_map *m, uint64_t work_items, int per_cu) {
+    uint64_t blocks = (work_items + NT - 1) / NT;
+    uint64_t cap = (uint64_t)m->cus * per_cu;
+    return (int)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+
+#define DISPATCH_WK(m, CALL)                         \
+    switch ((m)->p.wk) {                             \
+        case 1: { constexpr int WKV = 1; CALL; } break; \
+        case 2: { constexpr int WKV = 2; CALL; } break; \
+        case 3: { constexpr int WKV = 3; CALL; } break; \
+        default: { constexpr int WKV = 4; CALL; } break; \
+    }
+
+// One FASTQ piece already on the device: passes 1-3.  own_end = number of start
+// positions this piece owns (bytes past it are halo for windows that begin
+// before it); head_open = the piece starts in the middle of a line.
+static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
+                           hipStream_t st) {
+    if (own_end == 0) return TSX_HIP_OK;
+    const uint64_t ntiles = (own_end + TILE - 1) / TILE;
+    if (ntiles > m->tile_cap) {
+        if (m->d_tile) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(m->d_tile)); m->d_tile = nullptr; }
+        m->tile_cap = ntiles + ntiles / 4 + 1024;
+        HIP_TRY(hipMalloc((void **)&m->d_tile, m->tile_cap * sizeof(uint32_t)));
+    }
+    const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
+    hipLaunchKernelGGL(line_count_kernel, dim3(g1), dim3(NT), 0, st, d_text, n, own_end, head_open, m->d_tile, ntiles);
+    hipLaunchKernelGGL(line_scan_kernel, dim3(1), dim3(1024), 0, st, m->d_tile, ntiles, m->d_carry);
+    const size_t lut_bytes = m->lut.size() * 8;
+    const int g3 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3);
+    DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
+                                      own_end, head_open, (const uint32_t *)m->d_tile, ntiles));
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream) {
+    if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15)) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    return run_fastq_piece(m, (const uint8_t *)dev_text, n, n, 0, st);
+}
+
+static int ensure_staging(tsx_hip_map *m) {
+    if (m->stage_bytes) return TSX_HIP_OK;
+    const size_t bytes = STAGE_PIECE + STAGE_PAD;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipHostMalloc((void **)&m->h_stage[i], bytes, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&m->d_stage[i], bytes));
+        HIP_TRY(hipEventCreateWithFlags(&m->stage_done[i], hipEventDisableTiming));
+    }
+    m->stage_bytes = bytes;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n) {
+    if (!m || (!text && n)) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = ensure_staging(m);
+    if (rc != TSX_HIP_OK) return rc;
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    // Pieces own STAGE_PIECE start positions and carry a k-1 byte halo so that
+    // windows beginning near the end of a piece see their last bytes.
+    const size_t halo = (size_t)m->p.k - 1;
+    int buf = 0;
+    bool used[2] = {false, false};
+    for (size_t off = 0; off < n; off += STAGE_PIECE, buf ^= 1) {
+        const size_t own = std::min(STAGE_PIECE, n - off);
+        const size_t len = std::min(own + halo, n - off);
+        if (used[buf]) HIP_TRY(hipEventSynchronize(m->stage_done[buf]));
+        memcpy(m->h_stage[buf], text + off, len);
+        HIP_TRY(hipMemcpyAsync(m->d_stage[buf], m->h_stage[buf], len, hipMemcpyHostToDevice, st));
+        const int head_open = (off > 0 && text[off - 1] != '\n') ? 1 : 0;
+        rc = run_fastq_piece(m, m->d_stage[buf], len, own, head_open, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipEventRecord(m->stage_done[buf], st));
+        used[buf] = true;
+    }
+    return tsx_hip_sync(m);
+}
+
+extern "C" int tsx_hip_add_kmers_device(tsx_hip_map *m, const void *dev_kmers, const void *dev_counts, size_t n,
+                                        void *stream) {
+    if (!m || (!dev_kmers && n)) return TSX_HIP_EINVAL;
+    if (n == 0) return TSX_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    const int grid = grid_for(m, n, 8);
+    DISPATCH_WK(m, hipLaunchKernelGGL((add_kmers_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p,
+                                      (const uint64_t *)dev_kmers, (const uint64_t *)dev_counts, (uint64_t)n));
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_add_kmers_host(tsx_hip_map *m, const uint64_t *kmers, const uint64_t *counts, size_t n) {
+    if (!m || (!kmers && n)) return TSX_HIP_EINVAL;
+    if (n == 0) return TSX_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    uint64_t *dk = nullptr, *dc = nullptr;
+    const size_t kb = n * (size_t)m->p.wk * 8;
+    HIP_TRY(hipMalloc((void **)&dk, kb));
+    int rc = TSX_HIP_OK;
+    do {
+        if (hipMemcpyAsync(dk, kmers, kb, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        if (counts) {
+            if (hipMalloc((void **)&dc, n * 8) != hipSuccess) { rc = TSX_HIP_ENOMEM; break; }
+            if (hipMemcpyAsync(dc, counts, n * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        }
+        rc = tsx_hip_add_kmers_device(m, dk, dc, n, nullptr);
+        if (rc == TSX_HIP_OK) rc = tsx_hip_sync(m);
+    } while (0);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(dk); (void)hipFree(dc);
+    return rc;
+}
+
+extern "C" int tsx_hip_get_counts_device(tsx_hip_map *m, const void *dev_kmers, size_t n, void *dev_counts_out,
+                                         void *stream) {
+    if (!m || ((!dev_kmers || !dev_counts_out) && n)) return TSX_HIP_EINVAL;
+    if (n == 0) return TSX_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    const int grid = grid_for(m, n, 8);
+    DISPATCH_WK(m, hipLaunchKernelGGL((get_counts_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p,
+                                      (const uint64_t *)dev_kmers, (uint64_t)n, (uint64_t *)dev_counts_out));
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out) {
+    if (!m || ((!kmers || !counts_out) && n)) return TSX_HIP_EINVAL;
+    if (n == 0) return TSX_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    uint64_t *dk = nullptr, *dc = nullptr;
+    const size_t kb = n * (size_t)m->p.wk * 8;
+    HIP_TRY(hipMalloc((void **)&dk, kb));
+    if (hipMalloc((void **)&dc, n * 8) != hipSuccess) { (void)hipFree(dk); return TSX_HIP_ENOMEM; }
+    int rc = TSX_HIP_OK;
+    do {
+        if (hipMemcpyAsync(dk, kmers, kb, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        rc = tsx_hip_get_counts_device(m, dk, n, dc, nullptr);
+        if (rc != TSX_HIP_OK) break;
+        if (hipMemcpyAsync(counts_out, dc, n * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        if (hipStreamSynchronize(m->stream) != hipSuccess) rc = TSX_HIP_EHIP;
+    } while (0);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(dk); (void)hipFree(dc);
+    return rc;
+}
+
+extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
+    if (!m || !out) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemsetAsync(m->p.stats + ST_SCRATCH, 0, 2 * sizeof(unsigned long long), m->stream));
+    const int grid = grid_for(m, m->lay.slots, 8);
+    hipLaunchKernelGGL(occupied_kernel, dim3(grid), dim3(NT), 0, m->stream, m->p);
+    HIP_TRY(hipGetLastError());
+    unsigned long long st[ST_N];
+    int rc = read_stats(m, st);
+    if (rc != TSX_HIP_OK) return rc;
+    out->kmers_added = st[ST_KMERS];
+    out->insert_failures = st[ST_FAIL];
+    out->overflow_carries = st[ST_CARRY];
+    out->overflow_failures = st[ST_SECFAIL];
+    out->lock_timeouts = st[ST_LOCKTO];
+    out->distinct = st[ST_SCRATCH];
+    out->overflow_used = st[ST_SCRATCH2];
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_partition_device(tsx_hip_map *m, int nranks, void *dev_kmers_out, void *dev_counts_out,
+                                        size_t cap, void *dev_seg_counts, void *stream) {
+    if (!m || nranks < 1 || nranks > 64 || !dev_kmers_out || !dev_counts_out || !dev_seg_counts) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    const int grid = grid_for(m, m->lay.slots, 8);
+    unsigned long long *seg = m->d_seg;
+    HIP_TRY(hipMemsetAsync(seg, 0, 64 * sizeof(unsigned long long), st));
+    DISPATCH_WK(m, hipLaunchKernelGGL((dump_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p, nranks, 0,
+                                      (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, seg));
+    // segment sizes -> caller; exclusive prefix -> cursors (tiny: done on the host)
+    unsigned long long h_seg[64];
+    HIP_TRY(hipMemcpyAsync(h_seg, seg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    unsigned long long cur[64], total = 0;
+    for (int r = 0; r < 64; ++r) { cur[r] = total; total += (r < nranks) ? h_seg[r] : 0; }
+    if (total > cap) return TSX_HIP_ERANGE;
+    HIP_TRY(hipMemcpyAsync(dev_seg_counts, h_seg, (size_t)nranks * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(seg, cur, 64 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    DISPATCH_WK(m, hipLaunchKernelGGL((dump_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p, nranks, 1,
+                                      (uint64_t *)dev_kmers_out, (uint64_t *)dev_counts_out, (uint64_t)cap, seg));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // cur[] lives on this stack frame
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_dump_device(tsx_hip_map *m, void *dev_kmers_out, void *dev_counts_out, size_t cap,
+                                   void *dev_n, void *stream) {
+    if (!dev_n) return TSX_HIP_EINVAL;
+    return tsx_hip_partition_device(m, 1, dev_kmers_out, dev_counts_out, cap, dev_n, stream);
+}
+
+extern "C" int tsx_hip_dump_host(tsx_hip_map *m, uint64_t *kmers_out, uint64_t *counts_out, size_t cap,
+                                 size_t *n_out) {
+    if (!m || !kmers_out || !counts_out || !n_out) return TSX_HIP_EINVAL;
+    tsx_hip_stats s;
+    int rc = tsx_hip_get_stats(m, &s);
+    if (rc != TSX_HIP_OK) return rc;
+    if (s.distinct > cap) return TSX_HIP_ERANGE;
+    *n_out = (size_t)s.distinct;
+    if (s.distinct == 0) return TSX_HIP_OK;
+    uint64_t *dk = nullptr, *dc = nullptr, *dn = nullptr;
+    const size_t kb = (size_t)s.distinct * m->p.wk * 8;
+    HIP_TRY(hipMalloc((void **)&dk, kb));
+    if (hipMalloc((void **)&dc, s.distinct * 8) != hipSuccess) { (void)hipFree(dk); return TSX_HIP_ENOMEM; }
+    if (hipMalloc((void **)&dn, 64) != hipSuccess) { (void)hipFree(dk); (void)hipFree(dc); return TSX_HIP_ENOMEM; }
+    rc = tsx_hip_dump_device(m, dk, dc, (size_t)s.distinct, dn, nullptr);
+    if (rc == TSX_HIP_OK) {
+        if (hipMemcpy(kmers_out, dk, kb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(counts_out, dc, s.distinct * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = TSX_HIP_EHIP;
+    }
+    (void)hipFree(dk); (void)hipFree(dc); (void)hipFree(dn);
+    return rc;
+}
+
+extern "C" int tsx_hip_owner_host(const tsx_hip_map *m, const uint64_t *kmer, int nranks) {
+    if (!m || !kmer || nranks < 1) return TSX_HIP_EINVAL;
+    uint64_t z = 0x243F6A8885A308D3ULL;
+    for (int t = 0; t < m->p.wk; ++t) {
+        uint64_t x = (t == m->p.wk - 1) ? (kmer[t] & m->p.top_mask) : kmer[t];
+        z ^= x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        z = z ^ (z >> 31);
+    }
+    return (int)((z >> 32) * (uint64_t)nranks >> 32);
+}
+
+extern "C" int tsx_hip_hash_apply(const tsx_hip_map *m, const uint64_t *kmer, uint64_t *key_out) {
+    if (!m || !kmer || !key_out) return TSX_HIP_EINVAL;
+    std::vector<uint64_t> x(kmer, kmer + m->p.wk);
+    x[m->p.wk - 1] &= m->p.top_mask;
+    apply_rows(m, m->rows, x.data(), key_out);
+    return TSX_HIP_OK;
+}
+extern "C" int tsx_hip_hash_invert(const tsx_hip_map *m, const uint64_t *key, uint64_t *kmer_out) {
+    if (!m || !key || !kmer_out) return TSX_HIP_EINVAL;
+    std::vector<uint64_t> x(key, key + m->p.wk);
+    x[m->p.wk - 1] &= m->p.top_mask;
+    apply_rows(m, m->irows, x.data(), kmer_out);
+    return TSX_HIP_OK;
+}
+extern "C" int tsx_hip_hash_rows(const tsx_hip_map *m, uint64_t *rows_out) {
+    if (!m || !rows_out) return TSX_HIP_EINVAL;
+    memcpy(rows_out, m->rows.data(), m->rows.size() * 8);
+    return TSX_HIP_OK;
+}
+
+// ---- synthetic reads -----------------------------------------------------------
+static inline int dec_digits(uint64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+
+extern "C" int tsx_hip_synth_fastq_device(uint64_t seed, uint64_t first_read, uint64_t n_reads, int k,
+                                          void *dev_out, size_t cap, uint64_t *bytes_out, uint64_t *kmers_out,
+                                          uint64_t *polya_kmers_out, int device, void *stream) {
+    if (k < 1 || k > 127) return TSX_HIP_EINVAL;
+    std::vector<uint64_t> offs(n_reads + 1);
+    uint64_t total = 0, kmers = 0, polya = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        const uint64_t id = first_read + r;
+        const uint32_t nrand = 500u + (uint32_t)(synth_mix(seed, id, 0) % 501u);
+        const uint32_t na = 100u + (uint32_t)(synth_mix(seed, id, 1) % 201u);
+        const uint64_t L = (uint64_t)nrand + na;
+        offs[r] = total;
+        total += 4 + dec_digits(id) + 1 + 2 * L + 4;
+        if (L >= (uint64_t)k) kmers += L - k + 1;
+        if (polya_kmers_out) {
+            // all-'A' windows: runs of A inside the random part plus the tail
+            uint32_t run = 0;
+            for (uint32_t j = 0; j < nrand; ++j) {
+                const uint64_t w = synth_mix(seed, id, 2 + (j >> 5));
+                if (((w >> (2 * (j & 31))) & 3) == 0) ++run;
+                else { if (run >= (uint32_t)k) polya += run - k + 1; run = 0; }
+            }
+            run += na;
+            if (run >= (uint32_t)k) polya += run - k + 1;
+        }
+    }
+    offs[n_reads] = total;
+    if (bytes_out) *bytes_out = total;
+    if (kmers_out) *kmers_out = kmers;
+    if (polya_kmers_out) *polya_kmers_out = polya;
+    if (!dev_out) return TSX_HIP_OK;
+    if (total > cap) return TSX_HIP_ERANGE;
+    if (n_reads == 0) return TSX_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TSX_HIP_ENODEVICE;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *d_off = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_off, (n_reads + 1) * 8));
+    int rc = TSX_HIP_OK;
+    if (hipMemcpyAsync(d_off, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = TSX_HIP_EHIP;
+    if (rc == TSX_HIP_OK) {
+        const int grid = (int)std::min<uint64_t>(n_reads, 65536);
+        hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(NT), 0, st, seed, first_read, n_reads,
+                           (const uint64_t *)d_off, (uint8_t *)dev_out);
+        if (hipGetLastError() != hipSuccess) rc = TSX_HIP_EHIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) rc = TSX_HIP_EHIP;
+    (void)hipFree(d_off);
+    return rc;
+}
