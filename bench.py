@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/sec inserted, k=31, synthetic FASTQ, --mode=HIP hot path.
+
+One "step" = one pass of the hot path over one batch: clear the table, then
+FASTQ scan -> 2-bit encode -> hash -> dedup -> insert for ~1e9 k-mers per GPU of
+synthetic reads (generateFakeSequences.py shape) already resident in HBM; with
+N > 1 ranks (one process per GPU, reads sharded, weak scaling) the step ends
+with the table merge over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(k, seed, max_seconds=90):
+    """Time the real reference (oracle/_ref/tsxCount_ref, --mode=CAS) on a bounded
+    sample of the same synthetic reads, on this box's host cores."""
+    from tsxcount_amd import synth
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "tsxCount_ref")
+    n_reads = 3000
+    text = synth.fastq(seed, 0, n_reads)
+    nrand, na = synth.read_lengths(seed, 0, n_reads)
+    kmers = int(((nrand + na) - k + 1).clip(min=0).sum())
+    # The reference's CAS mode live-locks on this input at 16 threads on the GPU box
+    # (unsynchronised retries, "INC KEY VAL CAS 0"); 8 threads completes.
+    cores = max(1, min(8, os.cpu_count() or 1))
+    sample = "%d synthetic reads (%d k-mers), k=%d" % (n_reads, kmers, k)
+    if os.path.exists(ref_bin):
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "sample.fastq")
+            with open(path, "wb") as f:
+                f.write(text)
+            # 2k+s must be a multiple of 8 for the reference's byte-wise CAS
+            # stores to stay aligned (TSXHashMapCAS.h:141-232): k=31 -> s=2.
+            cmd = [ref_bin, "--input=" + path, "--k=%d" % k, "--l=23", "--s=2", "--mode=CAS",
+                   "--threads=%d" % cores]
+            t0 = time.time()
+            try:
+                rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    timeout=max_seconds).returncode
+            except subprocess.TimeoutExpired:
+                rc = -1
+            dt = time.time() - t0
+        if rc == 0:
+            return {"value": kmers / dt, "unit": "k-mers/s", "cores": cores, "kind": "reference",
+                    "sample": sample + ", tsxCount --mode=CAS --l=23 --s=2, wall time of the whole run"}
+    # fall back to the C restatement (single core)
+    from oracle.oracle import Oracle
+    o = Oracle(k, 23, 2, seed=1)
+    t0 = time.time()
+    o.count_fastq(text)
+    dt = time.time() - t0
+    return {"value": kmers / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": sample + ", oracle/tsx_oracle.c serial"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--l", type=int, default=31, help="log2 table slots per GPU")
+    ap.add_argument("--reads", type=int, default=1087000, help="synthetic reads per GPU (~1e9 k-mers at k=31)")
+    ap.add_argument("--seed", type=int, default=20261004)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import tsxcount_amd as T
+    from tsxcount_amd import distributed as TD
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # synthetic input straight into HBM; every rank owns its own read shard
+    first = rank * args.reads
+    nbytes, kmers_rank, _ = T.synth_sizes(args.seed, first, args.reads, args.k)
+    text = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
+    T.synth_fastq_device(args.seed, first, args.reads, args.k, text.data_ptr(), nbytes, device=local_rank)
+
+    m = T.TSXHashMapHIP(args.l, 0, args.k, device=local_rank)
+
+    def step():
+        m.clear()
+        m.countFastqDevice(text.data_ptr(), nbytes)
+        if world > 1:
+            TD.merge_tables(m)
+        else:
+            m.sync()
+
+    for _ in range(args.warmup):
+        step()
+    m.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, count_ms, launches = m.get_timing()
+    m.set_timing(False)
+
+    # max over ranks
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        kt = torch.tensor([kmers_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(kt, op=dist.ReduceOp.SUM)
+        kmers_total = int(kt.item())
+    else:
+        kmers_total = kmers_rank
+
+    st = m.stats()
+    check_ok = (st["insert_failures"] == 0 and st["overflow_failures"] == 0 and st["lock_timeouts"] == 0)
+    if world == 1:
+        check_ok = check_ok and st["kmers_added"] == kmers_rank
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = kmers_total * args.steps / elapsed
+        # roofline of the dominant kernel (count_fastq_kernel): algorithmic bytes per launch
+        # = FASTQ bytes read once + 16 B (8 B slot read + 8 B slot write) per k-mer occurrence
+        kern_ms = count_ms / max(launches, 1)
+        alg_bytes = nbytes + 16.0 * kmers_rank
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "k-mers/sec inserted, k=31, 1e9 synthetic k-mers, 1/2/4/8 GPU; --check pass",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "synthetic FASTQ (generateFakeSequences.py shape), %d reads/GPU = %d k-mers/GPU, "
+                                   "k=%d, table 2^%d slots/GPU%s" % (args.reads, kmers_rank, args.k, args.l,
+                                                                      ", per-GPU tables merged over RCCL all-to-all"
+                                                                      if world > 1 else ""),
+                       "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
+                       "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL"},
+            "roofline": {"bound": "hbm", "kernel": "count_fastq_kernel<1>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel_ms": kern_ms, "line_pass_ms": scan_ms / max(launches, 1),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.k, args.seed)
+        elif world > 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,6 +110,16 @@ int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n);
 int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream);
 
 /*
+ * Measurement hooks (no reference counterpart): with timing enabled every
+ * FASTQ piece records HIP events on its launch stream around the line passes
+ * and around count_fastq_kernel.  get_timing waits for them, returns the
+ * summed milliseconds and the number of count_fastq_kernel launches, and
+ * resets the accumulation.
+ */
+int tsx_hip_set_timing(tsx_hip_map *m, int enable);
+int tsx_hip_get_timing(tsx_hip_map *m, double *scan_ms, double *count_ms, uint64_t *launches);
+
+/*
  * TSXHashMap::addKmer (TSXHashMap.h:182; CAS variant TSXHashMapCAS.h:268) for
  * a batch of n encoded k-mers; counts == NULL adds 1 per k-mer, otherwise
  * counts[i] occurrences (used by the multi-GPU merge).

@@ -1,0 +1,45 @@
+import gzip
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_fastq():
+    """data/small_t7.1000.fastq from the reference (a data fixture, 250 reads)."""
+    with open(os.path.join(GOLDEN, "small_t7.1000.fastq"), "rb") as f:
+        return f.read()
+
+
+@pytest.fixture(scope="session")
+def golden_counts():
+    """data/small_t7.1000.fastq.14.count from the reference: {kmer: count}, k=14."""
+    ref = {}
+    with gzip.open(os.path.join(GOLDEN, "small_t7.1000.fastq.14.count.gz"), "rt") as f:
+        for line in f:
+            a, b = line.rstrip("\n").split("\t")
+            ref[a] = int(b)
+    return ref
+
+
+def python_counts(text, k):
+    """Independent dictionary count of a FASTQ text with the reference's record
+    rules (FastXReader.h:359-372, testExecution.h:15-36)."""
+    from collections import Counter
+    lines = [l for l in text.split(b"\n") if len(l) > 0]
+    c = Counter()
+    for seq in lines[1::4]:
+        for i in range(len(seq) - k + 1):
+            c[seq[i:i + k]] += 1
+    return c

@@ -1,0 +1,88 @@
+"""N > 1 path on CPU: two gloo ranks shard the reads, count their shard into a
+local table (the oracle stands in for the GPU table here), and run the SAME
+exchange_segments() the GPU path uses; the merged result must equal a single
+table over all reads."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _owner(kmer_row, nranks):
+    # same function as owner_of()/tsx_hip_owner_host (splitmix finaliser chain)
+    M = (1 << 64) - 1
+    z = 0x243F6A8885A308D3
+    for x in kmer_row:
+        z ^= int(x)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z = z ^ (z >> 31)
+    return ((z >> 32) * nranks) >> 32
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle import Oracle
+    from tsxcount_amd import synth
+    from tsxcount_amd.distributed import exchange_segments, shard_reads
+    k, n_reads = 21, 48
+    first, cnt = shard_reads(n_reads, rank, world)
+    o = Oracle(k, 18, 4, seed=1)
+    o.count_fastq(synth.fastq(77, first, cnt))
+    kmers, counts = o.dump()
+    owner = np.array([_owner(r, world) for r in kmers], dtype=np.int64)
+    order = np.argsort(owner, kind="stable")
+    seg = np.bincount(owner, minlength=world).astype(np.int64)
+    rk, rc = exchange_segments(torch.from_numpy(kmers[order].view(np.int64)),
+                               torch.from_numpy(counts[order].view(np.int64)), torch.from_numpy(seg))
+    merged = Oracle(k, 18, 4, seed=1)
+    rk = rk.numpy().view(np.uint64)
+    rc = rc.numpy().view(np.uint64)
+    got = {}
+    for i in range(rk.shape[0]):
+        assert _owner(rk[i], world) == rank
+        key = rk[i].tobytes()
+        got[key] = got.get(key, 0) + int(rc[i])
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_merge_equals_single_table():
+    sys.path.insert(0, ROOT)
+    from oracle.oracle import Oracle
+    from tsxcount_amd import synth
+    from tsxcount_amd.distributed import shard_reads
+    assert shard_reads(10, 0, 3) == (0, 4) and shard_reads(10, 1, 3) == (4, 3) and shard_reads(10, 2, 3) == (7, 3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = Oracle(21, 18, 4, seed=1)
+    whole.count_fastq(synth.fastq(77, 0, 48))
+    kmers, counts = whole.dump()
+    expect = {kmers[i].tobytes(): int(counts[i]) for i in range(len(kmers))}
+    merged = {}
+    for r in (0, 1):
+        assert not (set(results[r]) & set(merged))  # owners are disjoint
+        merged.update(results[r])
+    assert merged == expect

@@ -1,0 +1,402 @@
+"""Parity of the HIP path (through the C ABI) with the oracle, the reference's
+golden fixture and size-independent properties.  Bit-exact: counts are integers."""
+import ctypes
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, python_counts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tsxcount_amd
+    assert os.path.exists(tsxcount_amd.LIB_PATH), "HIP extension missing: no fallback"
+    assert tsxcount_amd.lib().tsx_hip_device_count() > 0, "no GPU"
+    return tsxcount_amd
+
+
+def oracle_for(text, k, l=20, s=4):
+    from oracle.oracle import Oracle
+    o = Oracle(k, l, s, seed=1)
+    n = o.count_fastq(text)
+    return o, n
+
+
+def assert_same_as_oracle(T, text, k, l, s=0, **kw):
+    o, n = oracle_for(text, k, min(max(l, 16), 2 * k - 1), 4)
+    m = T.TSXHashMapHIP(l, s, k, **kw)
+    try:
+        m.countFastq(text)
+        st = m.stats()
+        assert st["kmers_added"] == n
+        assert st["distinct"] == o.distinct()
+        assert st["insert_failures"] == 0 and st["overflow_failures"] == 0 and st["lock_timeouts"] == 0
+        kmers, counts = o.dump()
+        if len(kmers):
+            assert np.array_equal(m.getKmerCounts(kmers), counts)
+        # and the other direction: everything the table holds is in the oracle
+        gk, gc = m.getAllKmers()
+        assert len(gk) == len(kmers)
+        assert int(gc.sum()) == n
+        if len(gk):
+            a = np.lexsort(gk.T[::-1])
+            b = np.lexsort(kmers.T[::-1])
+            assert np.array_equal(gk[a], kmers[b]) and np.array_equal(gc[a], counts[b])
+        return st
+    finally:
+        m.close()
+
+
+# --- the reference's own fixture -------------------------------------------------
+
+@pytest.mark.parametrize("l,s", [(26, 4), (20, 0), (18, 2), (18, 1)])
+def test_golden_fixture(T, golden_fastq, golden_counts, l, s):
+    m = T.TSXHashMapHIP(l, s, 14)
+    m.countFastq(golden_fastq)
+    st = m.stats()
+    assert st["kmers_added"] == 202204 and st["distinct"] == 194697
+    kmers = T.encode_many(list(golden_counts.keys()), 14)
+    exp = np.array(list(golden_counts.values()), dtype=np.uint64)
+    assert np.array_equal(m.getKmerCounts(kmers), exp)
+    m.close()
+
+
+def test_cli_check_passes_on_golden(T, tmp_path):
+    """tsxCount --input=... --mode=HIP --check, the README's test (README.md:47-52)."""
+    fq = tmp_path / "small_t7.1000.fastq"
+    fq.write_bytes(open(os.path.join(GOLDEN, "small_t7.1000.fastq"), "rb").read())
+    with gzip.open(os.path.join(GOLDEN, "small_t7.1000.fastq.14.count.gz"), "rb") as f:
+        (tmp_path / "small_t7.1000.fastq.14.count").write_bytes(f.read())
+    exe = os.path.join(ROOT, "tsxcount_amd", "bin", "tsxCount")
+    p = subprocess.run([exe, "--input=%s" % fq, "--mode=HIP", "--check", "--checkabort"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out + p.stderr.decode()
+    assert "Added a total of 194697 different kmers" in out
+    assert "total errors0" in out
+    assert "Reference kmer count: 194697" in out
+
+
+# --- oracle parity over k, table geometry and slot width ------------------------------
+
+@pytest.mark.parametrize("k,l,s", [
+    (5, 9, 0), (14, 16, 4), (21, 18, 0), (31, 18, 0), (31, 20, 4), (32, 18, 0), (32, 12, 0),
+    (33, 18, 0), (47, 18, 6), (63, 18, 0), (64, 19, 0), (65, 18, 3), (95, 18, 0), (96, 18, 0),
+    (97, 18, 0), (127, 18, 0), (127, 19, 2)])
+def test_parity_with_oracle(T, k, l, s):
+    from tsxcount_amd import synth
+    text = synth.fastq(100 + k, 0, 150 if k > 5 else 1)
+    if k == 5:
+        text = text[:400] + b"\n"  # at most ~390 distinct 5-mers for the 512-slot table
+    assert_same_as_oracle(T, text, k, l, s)
+
+
+def test_other_hash_seeds_give_the_same_counts(T):
+    from tsxcount_amd import synth
+    text = synth.fastq(4, 0, 80)
+    for seed in (2, 12345, 2 ** 63 + 11):
+        assert_same_as_oracle(T, text, 31, 18, 0, hash_seed=seed)
+
+
+def test_mapping_matches_oracle_and_inverts(T):
+    from oracle.oracle import Oracle
+    for k in (14, 31, 63, 127):
+        o = Oracle(k, 12, 4, seed=5)
+        m = T.TSXHashMapHIP(12, 0, k, hash_seed=5)
+        assert np.array_equal(m.hash_rows(), o.hash_rows())
+        rng = np.random.default_rng(k)
+        for _ in range(20):
+            x = rng.integers(0, 2 ** 63, size=m.wk, dtype=np.uint64)
+            x[-1] &= np.uint64((1 << ((2 * k) % 64 or 64)) - 1)
+            assert np.array_equal(m.hash_apply(x), o.hash_apply(x))
+            assert np.array_equal(m.hash_invert(m.hash_apply(x)), x)
+        m.close()
+
+
+# --- edge cases of the record rules ----------------------------------------------------
+
+EDGE_TEXTS = {
+    "empty": b"",
+    "only_newlines": b"\n\n\n",
+    "short_reads": b"@a\nACG\n+\n!!!\n@b\nAC\n+\n!!\n",
+    "no_trailing_newline": b"@a\nACGTACGTAC\n+\n!!!!!!!!!!\n@b\nTTTTTTTTTT\n+\n!!!!!!!!!!",
+    "empty_lines": b"\n@a\n\n\nACGTACGTACGT\n\n+\n\n!!!!!!!!!!!!\n\n\n@b\nGGGGGGGGGGGG\n+\n!!!!!!!!!!!!\n\n",
+    "exactly_k": b"@a\nACGTACGT\n+\n!!!!!!!!\n",
+    "with_N_and_lowercase": b"@a\nACGTNNACGTacgtNACGTTTGA\n+\n!!!!!!!!!!!!!!!!!!!!!!!!\n",
+    "crlf": b"@a\r\nACGTACGTACGT\r\n+\r\n!!!!!!!!!!!!\r\n",
+    "quality_starts_with_at": b"@a\nACGTACGTAAAA\n+\n@@@@@@@@@@@@\n@b\nCCCCCCCCACGT\n+\n@ACGTACGTACG\n",
+    "header_looks_like_sequence": b"ACGTACGTACGT\nTTTTTTTTTTTT\nACGTACGTACGT\nACGTACGTACGT\n",
+    "trailing_partial_record": b"@a\nACGTACGTACGT\n+\n!!!!!!!!!!!!\n@b\nGGGGGGGGGGGG\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(EDGE_TEXTS))
+def test_edge_cases(T, name):
+    assert_same_as_oracle(T, EDGE_TEXTS[name], 8, 12, 0)
+
+
+def test_long_reads_span_many_tiles(T):
+    # one 50 kb read (the bundled fixture has 20 kb reads) + long header and quality lines
+    rng = np.random.default_rng(3)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 50000)].tobytes()
+    text = b"@" + b"h" * 9000 + b"\n" + seq + b"\n+\n" + b"I" * 50000 + b"\n"
+    assert_same_as_oracle(T, text * 2, 31, 18, 0)
+    assert_same_as_oracle(T, text, 127, 18, 0)
+
+
+def test_piece_seams_of_the_host_path(T):
+    """The host entry point streams the text in pieces; seams fall inside lines,
+    inside k-mer windows and on newlines.  Small pieces force thousands of seams."""
+    from tsxcount_amd import synth
+    text = synth.fastq(8, 0, 60)
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; import tsxcount_amd as T;"
+            "from tsxcount_amd import synth; text = synth.fastq(8, 0, 60);"
+            "m = T.TSXHashMapHIP(18, 0, 31); m.countFastq(text); k, c = m.getAllKmers();"
+            "o = np.lexsort(k.T[::-1]); np.save(sys.argv[1], np.concatenate([k[o].ravel(), c[o]]))" % ROOT)
+    import tempfile
+    outs = []
+    for piece in ("4096", "5008", "65536"):
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "r.npy")
+            env = dict(os.environ, TSX_HIP_PIECE_BYTES=piece)
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+            outs.append(np.load(f))
+    o, n = oracle_for(text, 31, 18, 4)
+    kmers, counts = o.dump()
+    b = np.lexsort(kmers.T[::-1])
+    expect = np.concatenate([kmers[b].ravel(), counts[b]])
+    for got in outs:
+        assert np.array_equal(got, expect)
+
+
+def test_device_entry_point_equals_host_entry_point(T):
+    import torch
+    from tsxcount_amd import synth
+    text = synth.fastq(12, 0, 300)
+    dev = torch.device("cuda", 0)
+    buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    m = T.TSXHashMapHIP(20, 0, 31)
+    torch.cuda.synchronize()
+    m.countFastqDevice(buf.data_ptr(), len(text))
+    m.sync()
+    o, n = oracle_for(text, 31, 20, 4)
+    assert m.stats()["kmers_added"] == n and m.stats()["distinct"] == o.distinct()
+    kmers, counts = o.dump()
+    assert np.array_equal(m.getKmerCounts(kmers), counts)
+    # misaligned device pointers are refused, not silently mis-read
+    rc = m._lib.tsx_hip_count_fastq_device(m.handle, ctypes.c_void_p(buf.data_ptr() + 1), 100, None)
+    assert rc == T.EINVAL
+    m.close()
+
+
+def test_synth_kernel_matches_numpy_generator(T):
+    import torch
+    from tsxcount_amd import synth
+    for seed, first, n in ((5, 0, 37), (6, 123456, 20)):
+        text = synth.fastq(seed, first, n)
+        nb, nk, _ = T.synth_sizes(seed, first, n, 31)
+        buf = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        T.synth_fastq_device(seed, first, n, 31, buf.data_ptr(), nb)
+        assert bytes(buf[:nb].cpu().numpy().tobytes()) == text
+
+
+# --- insert / query surface -----------------------------------------------------------
+
+def test_add_and_get_surface(T):
+    m = T.TSXHashMapHIP(16, 0, 14)
+    assert m.getK() == 14 and m.getMaxElements() == 1 << 16
+    assert m.getKmerCount("ACGTACGTACGTAC") == 0
+    assert m.addKmer("ACGTACGTACGTAC") is True
+    m.addKmer(T.encode("ACGTACGTACGTAC"))
+    assert m.getKmerCount("ACGTACGTACGTAC") == 2
+    assert m.getKmerCount() == 1
+    # testExecution.h:406-496 (testHashMapOld): four k-mers, 196608 / 98304 / 98304 / 49152 adds
+    vals = [10067, 2786, 9816, 156]
+    n = 2048 * 4 * 24
+    seq = []
+    for i in range(n):
+        seq.append(vals[0])
+        seq.append(vals[1] if i % 2 == 0 else vals[2])
+        if i % 4 == 0:
+            seq.append(vals[3])
+    m.addKmers(np.array(seq, dtype=np.uint64))
+    got = m.getKmerCounts(np.array(vals, dtype=np.uint64))
+    assert list(map(int, got)) == [n, n // 2, n // 2, n // 4]
+    # weighted adds (merge path) and zero weights
+    m.addKmers(np.array([vals[0], 777], dtype=np.uint64), counts=np.array([5, 0], dtype=np.uint64))
+    assert m.getKmerCount(np.array([vals[0]], dtype=np.uint64)) == n + 5
+    assert m.getKmerCount(np.array([777], dtype=np.uint64)) == 0
+    m.clear()
+    assert m.getKmerCount() == 0 and m.stats()["kmers_added"] == 0
+    m.close()
+
+
+@pytest.mark.parametrize("k,s", [(14, 1), (14, 3), (31, 2), (63, 2), (127, 4)])
+def test_count_overflow_into_secondary_array(T, k, s):
+    """Hot k-mers far beyond 2^s: the in-slot counter wraps, carries go to the
+    secondary array (the reference chains overflow slots, TSXHashMapPerf.h:699-881)."""
+    rng = np.random.default_rng(k)
+    wk = T.key_limbs(k)
+    hot = rng.integers(0, 2 ** 62, size=(7, wk), dtype=np.uint64)
+    hot[:, -1] &= np.uint64((1 << ((2 * k) % 64 or 64)) - 1)
+    reps = [1, 2 ** s - 1, 2 ** s, 2 ** s + 1, 1000, 65537, 300000]
+    batch = np.concatenate([np.repeat(hot[i:i + 1], r, axis=0) for i, r in enumerate(reps)])
+    rng.shuffle(batch, axis=0)
+    m = T.TSXHashMapHIP(14, s, k)
+    assert m.layout.count_bits == s
+    m.addKmers(batch)
+    m.addKmers(hot, counts=np.array([3] * 7, dtype=np.uint64))
+    assert list(map(int, m.getKmerCounts(hot))) == [r + 3 for r in reps]
+    st = m.stats()
+    assert st["overflow_used"] >= 4 and st["overflow_failures"] == 0
+    gk, gc = m.getAllKmers()
+    assert sorted(map(int, gc)) == sorted(r + 3 for r in reps)
+    m.close()
+
+
+def test_secondary_array_full_is_reported(T):
+    m = T.TSXHashMapHIP(14, 1, 14, overflow_l=4)
+    kmers = np.arange(1, 2001, dtype=np.uint64)
+    with pytest.raises(T.TSXException) as e:
+        m.addKmers(np.repeat(kmers, 3))
+    assert e.value.code == T.EOVERFLOW
+    assert m.stats()["overflow_failures"] > 0
+    m.close()
+
+
+def test_table_full_is_reported_like_exit_42(T):
+    # more distinct k-mers than slots: reference prints "Could not insert kmer" and exit(42)
+    m = T.TSXHashMapHIP(8, 0, 14)
+    with pytest.raises(T.TSXException) as e:
+        m.addKmers(np.arange(1, 600, dtype=np.uint64))
+    assert e.value.code == T.EFULL
+    st = m.stats()
+    assert st["insert_failures"] > 0 and st["distinct"] <= 256
+    m.close()
+
+
+def test_high_load_factor(T):
+    """Load factor ~0.8 (BASELINE config 5 shape, scaled down): every key must
+    still be found with the 8-bit reprobe field."""
+    k = 127
+    n = int(0.8 * (1 << 16))
+    rng = np.random.default_rng(1)
+    kmers = rng.integers(0, 2 ** 62, size=(n, 4), dtype=np.uint64)
+    m = T.TSXHashMapHIP(16, 2, k)
+    m.addKmers(kmers)
+    m.addKmers(kmers[: n // 2])
+    got = m.getKmerCounts(kmers)
+    assert np.array_equal(got[: n // 2], np.full(n // 2, 2, dtype=np.uint64))
+    assert np.array_equal(got[n // 2:], np.full(n - n // 2, 1, dtype=np.uint64))
+    assert m.getKmerCount() == n
+    m.close()
+
+
+def test_zipf_skewed_reads_k63(T):
+    """BASELINE config 4 at oracle scale: Zipf-skewed reads, 2-limb keys, heavy
+    contention on a few k-mers and long reprobe chains."""
+    from tsxcount_amd import synth
+    text = synth.zipf_fastq(7, n_reads=3000, read_len=150, n_templates=400, k=63)
+    st = assert_same_as_oracle(T, text, 63, 17, 0)
+    assert st["kmers_added"] == 3000 * (150 - 63 + 1)
+    assert_same_as_oracle(T, text, 63, 17, 3)
+
+
+def test_dump_partition_by_owner(T):
+    import torch
+    from tsxcount_amd import synth
+    text = synth.fastq(31, 0, 100)
+    m = T.TSXHashMapHIP(18, 0, 31)
+    m.countFastq(text)
+    n = m.stats()["distinct"]
+    world = 4
+    dev = torch.device("cuda", 0)
+    kmers = torch.zeros((n, 1), dtype=torch.int64, device=dev)
+    counts = torch.zeros((n,), dtype=torch.int64, device=dev)
+    seg = torch.zeros((world,), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    T._check(m._lib.tsx_hip_partition_device(m.handle, world, ctypes.c_void_p(kmers.data_ptr()),
+                                             ctypes.c_void_p(counts.data_ptr()), n,
+                                             ctypes.c_void_p(seg.data_ptr()), None))
+    seg = seg.cpu().numpy()
+    assert int(seg.sum()) == n and (seg > 0).all()
+    k_np = kmers.cpu().numpy().view(np.uint64)
+    c_np = counts.cpu().numpy().view(np.uint64)
+    bounds = np.concatenate([[0], np.cumsum(seg)])
+    for r in range(world):
+        for i in range(bounds[r], bounds[r + 1], max(1, seg[r] // 50)):
+            assert m.owner(k_np[i], world) == r
+    o, _ = oracle_for(text, 31, 18, 4)
+    ok, oc = o.dump()
+    a, b = np.lexsort(k_np.T[::-1]), np.lexsort(ok.T[::-1])
+    assert np.array_equal(k_np[a], ok[b]) and np.array_equal(c_np[a], oc[b])
+    m.close()
+
+
+# --- BASELINE-size properties (no oracle at this size) ------------------------------------
+
+def test_full_size_properties(T):
+    """~1e8..1e9 k-mers, k=31: totals, the analytically known polyA count,
+    idempotence (counting the same text twice doubles every count, distinct
+    unchanged) and spot checks of sampled k-mers against a dictionary count of
+    their reads."""
+    import torch
+    from tsxcount_amd import synth
+    n_reads, k, seed = 300000, 31, 99
+    nb, nk, npolya = T.synth_sizes(seed, 0, n_reads, k, want_polya=True)
+    buf = torch.empty(nb + 64, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    T.synth_fastq_device(seed, 0, n_reads, k, buf.data_ptr(), nb)
+    m = T.TSXHashMapHIP(30, 0, k)
+    m.countFastqDevice(buf.data_ptr(), nb)
+    m.sync()
+    st = m.stats()
+    assert st["kmers_added"] == nk
+    assert st["insert_failures"] == 0 and st["overflow_failures"] == 0
+    polya = T.encode("A" * k)
+    assert m.getKmerCount(polya) == npolya
+    d1 = st["distinct"]
+    assert d1 < nk and d1 > nk - npolya - n_reads  # nearly everything else is unique
+    # sample reads: their k-mers must be present with at least the in-read multiplicity
+    nrand, na = synth.read_lengths(seed, 0, n_reads)
+    for r in (0, 1, 77777, n_reads - 1):
+        s = synth.read_sequence(seed, r, int(nrand[r]), int(na[r]))
+        ref = python_counts(b"@x\n" + s + b"\n+\n" + b"&" * len(s) + b"\n", k)
+        ref.pop(b"A" * k, None)
+        kk = T.encode_many(list(ref.keys()), k)
+        got = m.getKmerCounts(kk)
+        assert (got >= np.array(list(ref.values()), dtype=np.uint64)).all()
+        assert (got == np.array(list(ref.values()), dtype=np.uint64)).mean() > 0.99
+    # idempotence
+    m.countFastqDevice(buf.data_ptr(), nb)
+    m.sync()
+    st2 = m.stats()
+    assert st2["distinct"] == d1 and st2["kmers_added"] == 2 * nk
+    assert m.getKmerCount(polya) == 2 * npolya
+    m.close()
+
+
+def test_two_rank_merge_on_one_gpu():
+    """Two processes share cuda:0, count disjoint read shards into their own
+    tables and merge (gloo collective staged through host memory).  RCCL itself
+    needs one GPU per rank, which only the driver's multi-GPU node has."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(ROOT, "tests", "_merge_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "MERGE OK" in o

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -24,6 +25,8 @@ static thread_local std::string g_last_error;
             return (_e == hipErrorOutOfMemory) ? TSX_HIP_ENOMEM : TSX_HIP_EHIP;          \
         }                                                                                \
     } while (0)
+
+static const size_t STAGE_PIECE_DEFAULT = (size_t)64 << 20;  // bytes of FASTQ per host piece
 
 struct tsx_hip_map {
     TableParams p{};
@@ -44,10 +47,15 @@ struct tsx_hip_map {
     uint8_t *d_stage[2] = {nullptr, nullptr};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
+    size_t piece = STAGE_PIECE_DEFAULT;  // TSX_HIP_PIECE_BYTES overrides (tests exercise piece seams)
     int cus = 256;
+    // optional per-pass timing (HIP events on the launch stream)
+    int timing = 0;
+    int dbg = 0;                     // TSX_HIP_DEBUG: bit0 = skip the global insert (ablation builds only)
+    std::vector<hipEvent_t> ev;      // triples: before pass 1, before pass 3, after pass 3
+    size_t ev_used = 0;
 };
 
-static const size_t STAGE_PIECE = (size_t)64 << 20;  // bytes of FASTQ per host piece
 static const size_t STAGE_PAD = 256;
 
 extern "C" int tsx_hip_key_limbs(int k) { return (k < 1 || k > 127) ? TSX_HIP_EINVAL : (2 * k + 63) / 64; }
@@ -216,6 +224,11 @@ extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, 
         return TSX_HIP_ENODEVICE;
     }
     m->device = device; m->seed = hash_seed;
+    if (const char *e = getenv("TSX_HIP_DEBUG")) m->dbg = atoi(e);
+    if (const char *e = getenv("TSX_HIP_PIECE_BYTES")) {
+        const long long v = atoll(e);
+        if (v >= 256) m->piece = ((size_t)v + 15) & ~(size_t)15;
+    }
     auto fail = [&](int code) { tsx_hip_destroy(m); return code; };
 #define HIP_TRY_C(expr)                                                         \
     do {                                                                        \
@@ -264,6 +277,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
         if (m->d_stage[i]) (void)hipFree(m->d_stage[i]);
         if (m->stage_done[i]) (void)hipEventDestroy(m->stage_done[i]);
     }
+    for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -328,14 +342,49 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         m->tile_cap = ntiles + ntiles / 4 + 1024;
         HIP_TRY(hipMalloc((void **)&m->d_tile, m->tile_cap * sizeof(uint32_t)));
     }
+    hipEvent_t *ev = nullptr;
+    if (m->timing) {
+        if (m->ev_used + 3 > m->ev.size()) {
+            for (int i = 0; i < 3; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
+        }
+        ev = &m->ev[m->ev_used]; m->ev_used += 3;
+        HIP_TRY(hipEventRecord(ev[0], st));
+    }
     const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
     hipLaunchKernelGGL(line_count_kernel, dim3(g1), dim3(NT), 0, st, d_text, n, own_end, head_open, m->d_tile, ntiles);
     hipLaunchKernelGGL(line_scan_kernel, dim3(1), dim3(1024), 0, st, m->d_tile, ntiles, m->d_carry);
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     const size_t lut_bytes = m->lut.size() * 8;
     const int g3 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3);
     DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
-                                      own_end, head_open, (const uint32_t *)m->d_tile, ntiles));
+                                      own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
     HIP_TRY(hipGetLastError());
+    if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_set_timing(tsx_hip_map *m, int enable) {
+    if (!m) return TSX_HIP_EINVAL;
+    m->timing = enable ? 1 : 0;
+    m->ev_used = 0;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *scan_ms, double *count_ms, uint64_t *launches) {
+    if (!m) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    double a = 0, b = 0;
+    for (size_t i = 0; i + 3 <= m->ev_used; i += 3) {
+        HIP_TRY(hipEventSynchronize(m->ev[i + 2]));
+        float t1 = 0, t2 = 0;
+        HIP_TRY(hipEventElapsedTime(&t1, m->ev[i], m->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t2, m->ev[i + 1], m->ev[i + 2]));
+        a += t1; b += t2;
+    }
+    if (scan_ms) *scan_ms = a;
+    if (count_ms) *count_ms = b;
+    if (launches) *launches = m->ev_used / 3;
+    m->ev_used = 0;
     return TSX_HIP_OK;
 }
 
@@ -349,7 +398,7 @@ extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, 
 
 static int ensure_staging(tsx_hip_map *m) {
     if (m->stage_bytes) return TSX_HIP_OK;
-    const size_t bytes = STAGE_PIECE + STAGE_PAD;
+    const size_t bytes = m->piece + STAGE_PAD;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipHostMalloc((void **)&m->h_stage[i], bytes, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&m->d_stage[i], bytes));
@@ -366,13 +415,13 @@ extern "C" int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t
     if (rc != TSX_HIP_OK) return rc;
     hipStream_t st = m->stream;
     HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
-    // Pieces own STAGE_PIECE start positions and carry a k-1 byte halo so that
+    // Pieces own m->piece start positions and carry a k-1 byte halo so that
     // windows beginning near the end of a piece see their last bytes.
     const size_t halo = (size_t)m->p.k - 1;
     int buf = 0;
     bool used[2] = {false, false};
-    for (size_t off = 0; off < n; off += STAGE_PIECE, buf ^= 1) {
-        const size_t own = std::min(STAGE_PIECE, n - off);
+    for (size_t off = 0; off < n; off += m->piece, buf ^= 1) {
+        const size_t own = std::min(m->piece, n - off);
         const size_t len = std::min(own + halo, n - off);
         if (used[buf]) HIP_TRY(hipEventSynchronize(m->stage_done[buf]));
         memcpy(m->h_stage[buf], text + off, len);

@@ -1,0 +1,182 @@
+// main_hip.cpp -- the tsxCount command line (src/mains/main.cpp) with the one
+// new mode this repo adds: --mode=HIP.  Options, defaults, console lines and
+// the --check procedure follow main.cpp:30-40,404-507 and :222-396; the CPU
+// modes stay in the reference build.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "TSXHashMapHIP.h"
+
+struct arguments {
+    int k = 14, l = 26, storagebits = 4, threads = 0;  // main.cpp:410-413
+    std::string input_path, mode = "HIP";
+    bool check = false, checkabort = false;
+    unsigned long long seed = 1;
+    int device = 0;
+};
+
+static bool opt(const char *arg, const char *name, std::string &val) {
+    std::string a(arg), n = std::string("--") + name;
+    if (a == n) { val = ""; return true; }
+    if (a.compare(0, n.size() + 1, n + "=") == 0) { val = a.substr(n.size() + 1); return true; }
+    return false;
+}
+
+static int usage() {
+    std::cerr << "Usage: tsxCount --input=FASTQ[.gz] [--k=K] [--l=L] [--s=STORAGE] [--mode=HIP] [--threads=T]\n"
+                 "                [--check] [--checkabort] [--seed=S] [--device=D]\n"
+                 "Count k-mers on an MI355X. --check compares with FASTQ.<k>.count (kmer<TAB>count per line)."
+              << std::endl;
+    return 1;
+}
+
+// whole input in memory: plain files are mmap'ed, .gz goes through zlib
+// (FastXReader.h:178-206 picks zlib mode by the same suffix test)
+static bool load_input(const std::string &path, std::vector<char> &owned, const char *&text, size_t &n, void *&map) {
+    map = nullptr;
+    if (path.size() > 3 && path.rfind(".gz") == path.size() - 3) {
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) return false;
+        char buf[1 << 16];
+        int r;
+        while ((r = gzread(f, buf, sizeof buf)) > 0) owned.insert(owned.end(), buf, buf + r);
+        gzclose(f);
+        text = owned.data(); n = owned.size();
+        return r == 0;
+    }
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return false; }
+    n = (size_t)st.st_size;
+    if (n == 0) { close(fd); text = ""; return true; }
+    map = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) { map = nullptr; return false; }
+    text = (const char *)map;
+    return true;
+}
+
+int main(int argc, char *argv[]) {
+    arguments a;
+    for (int i = 1; i < argc; ++i) {
+        std::string v;
+        if (opt(argv[i], "k", v)) a.k = atoi(v.c_str());
+        else if (opt(argv[i], "l", v)) a.l = atoi(v.c_str());
+        else if (opt(argv[i], "s", v)) a.storagebits = atoi(v.c_str());
+        else if (opt(argv[i], "threads", v)) a.threads = atoi(v.c_str());
+        else if (opt(argv[i], "input", v)) a.input_path = v;
+        else if (opt(argv[i], "mode", v)) a.mode = v;
+        else if (opt(argv[i], "check", v)) a.check = true;
+        else if (opt(argv[i], "checkabort", v)) a.checkabort = true;
+        else if (opt(argv[i], "seed", v)) a.seed = strtoull(v.c_str(), nullptr, 10);
+        else if (opt(argv[i], "device", v)) a.device = atoi(v.c_str());
+        else if (opt(argv[i], "help", v)) return usage();
+        else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << std::endl; return usage(); }
+    }
+    std::transform(a.mode.begin(), a.mode.end(), a.mode.begin(), ::toupper);
+    if (a.input_path.empty()) return usage();
+
+    std::cout << "Running with parameters " << std::endl;
+    std::cerr << "K=" << a.k << std::endl;
+    std::cerr << "L=" << a.l << std::endl;
+    std::cerr << "StorageBits=" << a.storagebits << std::endl;
+    std::cerr << "Check=" << (a.check ? "Yes" : "No") << std::endl;
+    std::cerr << "Input=" << a.input_path << std::endl;
+    std::cerr << "Threads=" << a.threads << std::endl;
+    std::cerr << "Mode=" << a.mode << std::endl;
+    if (a.mode != "HIP") {
+        std::cerr << "This binary implements --mode=HIP only; SERIAL/PTHREAD/OMP/CAS/TSX are the reference's CPU modes."
+                  << std::endl;
+        return 2;
+    }
+
+    try {
+        std::cerr << "Creating TSXHashMap HIP" << std::endl;
+        TSXHashMapHIP oMap((uint8_t)a.l, (uint32_t)a.storagebits, (uint16_t)a.k, (uint8_t)a.threads, a.seed, a.device);
+
+        std::vector<char> owned;
+        const char *text = nullptr;
+        size_t n = 0;
+        void *map = nullptr;
+        if (!load_input(a.input_path, owned, text, n, map)) {
+            std::cerr << "Could not read " << a.input_path << std::endl;
+            return 3;
+        }
+        auto t0 = std::chrono::steady_clock::now();
+        oMap.countFastq(text, n);
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (map) munmap(map, n);
+        tsx_hip_stats st = oMap.stats();
+        std::cout << "Added a total of " << st.distinct << " different kmers" << std::endl;
+        std::cerr << "add calls: " << st.kmers_added << std::endl;
+        std::cerr << "count time [s]: " << dt << " (" << (dt > 0 ? st.kmers_added / dt : 0) << " k-mers/s, host to table)"
+                  << std::endl;
+
+        int rc = 0;
+        if (a.check) {  // main.cpp:224-396
+            std::string sRefFilename = a.input_path + "." + std::to_string(a.k) + ".count";
+            std::cout << "Checking kmer counts against manual hashmap ..." << std::endl;
+            std::cerr << "Loading reference file: " << sRefFilename << std::endl;
+            std::ifstream file(sRefFilename);
+            if (!file.is_open()) {
+                std::cerr << "Could not open " << sRefFilename << std::endl;
+                return 4;
+            }
+            const size_t wk = (size_t)oMap.getLayout().key_limbs;
+            std::vector<uint64_t> limbs, expect, got;
+            std::vector<std::string> names;
+            std::string line;
+            uint64_t iRefCount = 0, totalerrors = 0;
+            auto flush = [&]() {
+                if (expect.empty()) return;
+                oMap.getKmerCounts(limbs, expect.size(), got);
+                for (size_t i = 0; i < expect.size(); ++i)
+                    if (got[i] != expect[i]) {
+                        ++totalerrors;
+                        if (totalerrors <= 20)
+                            std::cout << "kmer: ( " << names[i] << " ): " << got[i] << " Should be " << expect[i] << std::endl;
+                        if (a.checkabort) exit(200);  // main.cpp:285-291
+                    }
+                std::cout << "Checked " << expect.size() << " kmers" << std::endl;
+                iRefCount += expect.size();
+                limbs.clear(); expect.clear(); names.clear();
+            };
+            while (std::getline(file, line)) {
+                size_t tab = line.find('\t');
+                if (tab == std::string::npos) continue;
+                std::string kmer = line.substr(0, tab);
+                if ((int)kmer.size() != a.k) continue;
+                tsx_kmer_t enc = oMap.fromSequence(kmer);
+                limbs.insert(limbs.end(), enc.begin(), enc.end());
+                expect.push_back(strtoull(line.c_str() + tab + 1, nullptr, 10));
+                names.push_back(kmer);
+                if (expect.size() >= 100000) flush();  // main.cpp:263
+            }
+            (void)wk;
+            flush();
+            std::cout << "total errors" << totalerrors << std::endl;
+            std::cout << "Kmer count check completed." << std::endl;
+            std::cout << "Reference kmer count: " << iRefCount << std::endl;
+            std::cout << "tsxCount kmer count: " << st.distinct << std::endl;
+            if (totalerrors || iRefCount != st.distinct) rc = 5;
+        }
+        oMap.print_stats();
+        return rc;
+    } catch (const TSXException &e) {
+        std::cerr << "TSXException: " << e.what() << std::endl;
+        return e.code() == TSX_HIP_EFULL ? 42 : 10;  // exit(42): TSXHashMap.h:340-343
+    }
+}
