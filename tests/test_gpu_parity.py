@@ -86,15 +86,16 @@ def test_cli_check_passes_on_golden(T, tmp_path):
 
 # --- oracle parity over k, table geometry and slot width ------------------------------
 
-@pytest.mark.parametrize("k,l,s", [
-    (5, 9, 0), (14, 16, 4), (21, 18, 0), (31, 18, 0), (31, 20, 4), (32, 18, 0), (32, 12, 0),
-    (33, 18, 0), (47, 18, 6), (63, 18, 0), (64, 19, 0), (65, 18, 3), (95, 18, 0), (96, 18, 0),
-    (97, 18, 0), (127, 18, 0), (127, 19, 2)])
-def test_parity_with_oracle(T, k, l, s):
+@pytest.mark.parametrize("k,l,s,reads", [
+    (5, 9, 0, 0), (14, 16, 4, 40), (21, 18, 0, 150), (31, 18, 0, 150), (31, 20, 4, 400), (32, 18, 0, 150),
+    (32, 12, 0, 2), (33, 18, 0, 150), (47, 18, 6, 150), (63, 18, 0, 150), (64, 19, 0, 150), (65, 18, 3, 150),
+    (95, 18, 0, 150), (96, 18, 0, 150), (97, 18, 0, 150), (127, 18, 0, 150), (127, 19, 2, 300)])
+def test_parity_with_oracle(T, k, l, s, reads):
     from tsxcount_amd import synth
-    text = synth.fastq(100 + k, 0, 150 if k > 5 else 1)
-    if k == 5:
-        text = text[:400] + b"\n"  # at most ~390 distinct 5-mers for the 512-slot table
+    if reads:
+        text = synth.fastq(100 + k, 0, reads)
+    else:  # k = 5: at most ~390 distinct 5-mers for the 512-slot table
+        text = synth.fastq(100 + k, 0, 1)[:400] + b"\n"
     assert_same_as_oracle(T, text, k, l, s)
 
 

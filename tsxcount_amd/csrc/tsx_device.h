@@ -142,11 +142,20 @@ __device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK],
     const int W = p.W;
     uint32_t i = 1;
     uint32_t spins = 0;
-    while (i <= p.max_reprobes) {
+    // `state`: 0 = still probing, 1 = placed, 2 = out of reprobes.  The loop has a
+    // single exit and no early return on purpose: a lane that claims a slot must
+    // publish its limbs and drop the lock INSIDE the iteration, before the wave
+    // branches back for the lanes that are still waiting on that very lock
+    // (wave64 lanes share one program counter; an exit path would be run only
+    // after every lane has left the loop).
+    int state = 0;
+    uint64_t carry = 0, carry_pos = 0;
+    while (state == 0) {
         const uint64_t pos = (pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.slot_mask;
         unsigned long long *e = (unsigned long long *)(p.table + pos * (uint64_t)W);
         const uint64_t key0 = e0 | i;
         const unsigned long long old = atomicCAS(e, 0ULL, (unsigned long long)(key0 | p.lock_bit | dlow));
+        bool next = false;
         if (old == 0ULL) {
             if (W > 1) {
                 for (int t = 1; t < W; ++t) atomicExch(e + t, (unsigned long long)hi[t - 1]);
@@ -154,23 +163,28 @@ __device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK],
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 atomicAnd(e, ~(unsigned long long)p.lock_bit);
             }
-            const uint64_t carry = d >> p.C;
-            if (carry) sec_add(p, pos, carry);
-            return true;
-        }
-        if ((old & p.k0mask) != key0) { ++i; continue; }
-        if (W > 1) {
-            if (old & p.lock_bit) {  // claimed, limbs not published yet: look again
-                if (++spins > (1u << 22)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); ++i; spins = 0; }
-                continue;
-            }
+            carry = d >> p.C; carry_pos = pos;
+            state = 1;
+        } else if ((old & p.k0mask) != key0) {
+            next = true;
+        } else if (W > 1 && (old & p.lock_bit)) {
+            // claimed, limbs not published yet: look again on the next iteration
+            if (++spins > (1u << 22)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); spins = 0; next = true; }
+        } else {
             bool same = true;
             for (int t = 1; t < W; ++t) same &= (atomicOr(e + t, 0ULL) == hi[t - 1]);
-            if (!same) { ++i; continue; }
+            if (same) {
+                const unsigned long long prev = atomicAdd(e, (unsigned long long)dlow);
+                carry = ((prev >> p.cshift) + d) >> p.C; carry_pos = pos;
+                state = 1;
+            } else {
+                next = true;
+            }
         }
-        const unsigned long long prev = atomicAdd(e, (unsigned long long)dlow);
-        const uint64_t carry = ((prev >> p.cshift) + d) >> p.C;
-        if (carry) sec_add(p, pos, carry);
+        if (next) { ++i; if (i > p.max_reprobes) state = 2; }
+    }
+    if (state == 1) {
+        if (carry) sec_add(p, carry_pos, carry);
         return true;
     }
     atomicAdd(&p.stats[ST_FAIL], (unsigned long long)d);
