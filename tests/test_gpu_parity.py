@@ -365,7 +365,9 @@ def test_full_size_properties(T):
     polya = T.encode("A" * k)
     assert m.getKmerCount(polya) == npolya
     d1 = st["distinct"]
-    assert d1 < nk and d1 > nk - npolya - n_reads  # nearly everything else is unique
+    # everything but polyA is unique except the ~10 windows per read that hold <= 9
+    # random bases in front of the A-tail (4^9 < n_reads, so they repeat across reads)
+    assert d1 < nk - npolya and d1 > nk - npolya - 12 * n_reads
     # sample reads: their k-mers must be present with at least the in-read multiplicity
     nrand, na = synth.read_lengths(seed, 0, n_reads)
     for r in (0, 1, 77777, n_reads - 1):
