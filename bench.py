@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--l", type=int, default=31, help="log2 table slots per GPU")
     ap.add_argument("--reads", type=int, default=1087000, help="synthetic reads per GPU (~1e9 k-mers at k=31)")
     ap.add_argument("--seed", type=int, default=20261004)
+    ap.add_argument("--path", default="auto", choices=["auto", "atomic", "partitioned"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,6 +101,7 @@ def main():
     T.synth_fastq_device(args.seed, first, args.reads, args.k, text.data_ptr(), nbytes, device=local_rank)
 
     m = T.TSXHashMapHIP(args.l, 0, args.k, device=local_rank)
+    m.set_path(args.path)
 
     def step():
         m.clear()
@@ -122,7 +124,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    scan_ms, count_ms, launches = m.get_timing()
+    scan_ms, count_ms, build_ms, launches = m.get_timing()
     m.set_timing(False)
 
     # max over ranks
@@ -170,6 +172,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "count_fastq_kernel<1>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kern_ms, "line_pass_ms": scan_ms / max(launches, 1),
+                         "partition_build_ms": build_ms / max(launches, 1),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -111,13 +111,23 @@ int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, v
 
 /*
  * Measurement hooks (no reference counterpart): with timing enabled every
- * FASTQ piece records HIP events on its launch stream around the line passes
- * and around count_fastq_kernel.  get_timing waits for them, returns the
- * summed milliseconds and the number of count_fastq_kernel launches, and
- * resets the accumulation.
+ * FASTQ piece records HIP events on its launch stream around the line passes,
+ * around count_fastq_kernel and around the partition + segment-build kernels.
+ * get_timing waits for them, returns the summed milliseconds of the three
+ * phases and the number of pieces (= count_fastq_kernel launches), and resets
+ * the accumulation.
  */
 int tsx_hip_set_timing(tsx_hip_map *m, int enable);
-int tsx_hip_get_timing(tsx_hip_map *m, double *scan_ms, double *count_ms, uint64_t *launches);
+int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
+                       uint64_t *launches);
+/*
+ * Insert path of the FASTQ entry points: 0 = choose per call (partitioned when
+ * the text is at least 1/32 of the table bytes and k <= 32), 1 = always the
+ * atomic path (one 64-bit CAS per distinct key), 2 = always the partitioned
+ * path (keys radix-scattered by table segment, segments built in LDS).  Both
+ * paths give identical tables up to slot order inside a segment.
+ */
+int tsx_hip_set_path(tsx_hip_map *m, int path);
 
 /*
  * TSXHashMap::addKmer (TSXHashMap.h:182; CAS variant TSXHashMapCAS.h:268) for

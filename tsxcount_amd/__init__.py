@@ -91,7 +91,9 @@ def lib():
     L.tsx_hip_hash_invert.argtypes = [vp, u64p, u64p]
     L.tsx_hip_hash_rows.argtypes = [vp, u64p]
     L.tsx_hip_set_timing.argtypes = [vp, ci]
-    L.tsx_hip_get_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), u64p]
+    L.tsx_hip_get_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_double), u64p]
+    L.tsx_hip_set_path.argtypes = [vp, ci]
     L.tsx_hip_synth_fastq_device.argtypes = [u64, u64, u64, ci, vp, sz, u64p, u64p, u64p, ci, vp]
     _lib = L
     return L
@@ -242,10 +244,15 @@ class TSXHashMapHIP:
         _check(self._lib.tsx_hip_set_timing(self._h, 1 if enable else 0))
 
     def get_timing(self):
-        """(line-pass ms, count_fastq_kernel ms, launches) since the last call."""
-        a, b, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_uint64(0)
-        _check(self._lib.tsx_hip_get_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
-        return a.value, b.value, int(n.value)
+        """(line-pass ms, count_fastq_kernel ms, partition+build ms, pieces) since the last call."""
+        a, b, c, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_uint64(0)
+        _check(self._lib.tsx_hip_get_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
+                                            ctypes.byref(n)))
+        return a.value, b.value, c.value, int(n.value)
+
+    def set_path(self, path):
+        """0 auto, 1 atomic, 2 partitioned (tsx_hip_set_path)."""
+        _check(self._lib.tsx_hip_set_path(self._h, {"auto": 0, "atomic": 1, "partitioned": 2}.get(path, path)))
 
     # --- mapping -------------------------------------------------------------
     def hash_rows(self):

@@ -40,12 +40,15 @@ struct TableParams {
     const uint64_t *lut;        // hash LUT   [groups][1<<g][WK]
     const uint64_t *ilut;       // inverse    [groups][1<<g][WK]
     uint64_t slot_mask;         // 2^l - 1
+    uint64_t seg_mask;          // 2^S - 1: probing never leaves the 2^S-slot segment of its home slot
+    uint8_t *seg_dirty;         // one byte per segment: 1 once the segment holds anything
     uint64_t sec_mask;
     uint64_t k0mask;            // key bits of limb 0
     uint64_t lock_bit;          // 0 when W == 1
     uint64_t top_mask;          // valid bits of the top key limb
     int k, l, n, wk, W;
     int R, F, C, K0, cshift;    // cshift = 64 - C
+    int S;                      // log2 slots per segment
     int g, groups;              // LUT granularity (4 or 8 bits) and group count
     uint32_t max_reprobes;
 };
@@ -102,6 +105,15 @@ __device__ inline uint64_t sec_get(const TableParams &p, uint64_t pos) {
     return 0;
 }
 
+// Probe sequence: the reference's pos = (key + i(i+1)/2) mod 2^l
+// (TSXHashMap.h:759-778,1046-1054) with the wrap-around taken inside the
+// 2^S-slot segment of the home slot, so that one workgroup can own a segment
+// (build_segments_kernel) and still probe exactly like the atomic path.
+// For l <= S this is the reference's formula.
+__device__ __forceinline__ uint64_t probe_pos(const TableParams &p, uint64_t pos0, uint32_t i) {
+    return (pos0 & ~p.seg_mask) | ((pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.seg_mask);
+}
+
 // Split a hashed key into what a slot stores: e0 = limb-0 key bits without the
 // reprobe count, hi[] = the func bits that spill into limbs 1..W-1.
 template <int WK>
@@ -151,12 +163,13 @@ __device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK],
     int state = 0;
     uint64_t carry = 0, carry_pos = 0;
     while (state == 0) {
-        const uint64_t pos = (pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.slot_mask;
+        const uint64_t pos = probe_pos(p, pos0, i);
         unsigned long long *e = (unsigned long long *)(p.table + pos * (uint64_t)W);
         const uint64_t key0 = e0 | i;
         const unsigned long long old = atomicCAS(e, 0ULL, (unsigned long long)(key0 | p.lock_bit | dlow));
         bool next = false;
         if (old == 0ULL) {
+            p.seg_dirty[pos >> p.S] = 1;  // idempotent plain store
             if (W > 1) {
                 for (int t = 1; t < W; ++t) atomicExch(e + t, (unsigned long long)hi[t - 1]);
                 // the limb stores must have landed before the slot is unlocked
@@ -199,7 +212,7 @@ __device__ inline uint64_t lookup_key(const TableParams &p, const uint64_t (&h)[
     split_key<WK>(p, h, pos0, e0, hi);
     const int W = p.W;
     for (uint32_t i = 1; i <= p.max_reprobes; ++i) {
-        const uint64_t pos = (pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.slot_mask;
+        const uint64_t pos = probe_pos(p, pos0, i);
         const uint64_t *e = p.table + pos * (uint64_t)W;
         const uint64_t v = e[0];
         if (v == 0) return 0;  // "why would the insertion skip an empty place?" TSXHashMap.h:622-626

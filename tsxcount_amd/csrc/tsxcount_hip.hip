@@ -3,6 +3,7 @@
 // tables, launches, staging copies.  No CPU counting path exists here.
 #include "../../include/tsxcount_hip.h"
 #include "tsx_kernels.h"
+#include "tsx_partition.h"
 
 #include <hip/hip_runtime.h>
 
@@ -49,10 +50,16 @@ struct tsx_hip_map {
     size_t stage_bytes = 0;
     size_t piece = STAGE_PIECE_DEFAULT;  // TSX_HIP_PIECE_BYTES overrides (tests exercise piece seams)
     int cus = 256;
+    // partitioned insert path (tsx_partition.h): grow-only scratch
+    int path = 0;                    // 0 auto, 1 atomic, 2 partitioned (tsx_hip_set_path / TSX_HIP_PATH)
+    uint64_t *d_buf[2] = {nullptr, nullptr};
+    size_t buf_bytes[2] = {0, 0};
+    unsigned long long *d_cnt = nullptr;   // [log regions | level-1 lists | segment lists]
+    size_t cnt_entries = 0;
     // optional per-pass timing (HIP events on the launch stream)
     int timing = 0;
     int dbg = 0;                     // TSX_HIP_DEBUG: bit0 = skip the global insert (ablation builds only)
-    std::vector<hipEvent_t> ev;      // triples: before pass 1, before pass 3, after pass 3
+    std::vector<hipEvent_t> ev;      // quads: before pass 1, before pass 3, after pass 3, after partition + build
     size_t ev_used = 0;
 };
 
@@ -193,6 +200,8 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l) {
     p.k0mask = (p.K0 >= 64) ? ~0ULL : ((1ULL << p.K0) - 1ULL);
     p.lock_bit = lock ? (1ULL << p.K0) : 0ULL;
     p.slot_mask = (1ULL << l) - 1ULL;
+    p.S = std::min(l, 14);           // 2^14 one-limb slots = 128 KiB: one segment fits a CU's LDS
+    p.seg_mask = (1ULL << p.S) - 1ULL;
     const uint64_t maxr = (1ULL << p.R) - 1ULL;
     p.max_reprobes = (uint32_t)std::min<uint64_t>(maxr, p.slot_mask);
     p.top_mask = (p.n & 63) ? ((1ULL << (p.n & 63)) - 1ULL) : ~0ULL;
@@ -225,6 +234,7 @@ extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, 
     }
     m->device = device; m->seed = hash_seed;
     if (const char *e = getenv("TSX_HIP_DEBUG")) m->dbg = atoi(e);
+    if (const char *e = getenv("TSX_HIP_PATH")) m->path = atoi(e);
     if (const char *e = getenv("TSX_HIP_PIECE_BYTES")) {
         const long long v = atoll(e);
         if (v >= 256) m->piece = ((size_t)v + 15) & ~(size_t)15;
@@ -248,6 +258,7 @@ extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, 
     HIP_TRY_C(hipMalloc((void **)&p.sec_keys, (p.sec_mask + 1) * 8));
     HIP_TRY_C(hipMalloc((void **)&p.sec_cnt, (p.sec_mask + 1) * 8));
     HIP_TRY_C(hipMalloc((void **)&p.stats, ST_N * sizeof(unsigned long long)));
+    HIP_TRY_C(hipMalloc((void **)&p.seg_dirty, (size_t)(m->lay.slots >> p.S)));
     HIP_TRY_C(hipMalloc((void **)&m->d_carry, 64));
     HIP_TRY_C(hipMalloc((void **)&m->d_seg, 64 * sizeof(unsigned long long)));
     make_mapping(m);
@@ -272,6 +283,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut);
     (void)hipFree(m->d_tile); (void)hipFree(m->d_carry); (void)hipFree(m->d_seg);
+    (void)hipFree(m->p.seg_dirty); (void)hipFree(m->d_buf[0]); (void)hipFree(m->d_buf[1]); (void)hipFree(m->d_cnt);
     for (int i = 0; i < 2; ++i) {
         if (m->h_stage[i]) (void)hipHostFree(m->h_stage[i]);
         if (m->d_stage[i]) (void)hipFree(m->d_stage[i]);
@@ -295,6 +307,7 @@ extern "C" int tsx_hip_clear(tsx_hip_map *m) {
     HIP_TRY(hipMemsetAsync(m->p.sec_keys, 0, (m->p.sec_mask + 1) * 8, m->stream));
     HIP_TRY(hipMemsetAsync(m->p.sec_cnt, 0, (m->p.sec_mask + 1) * 8, m->stream));
     HIP_TRY(hipMemsetAsync(m->p.stats, 0, ST_N * sizeof(unsigned long long), m->stream));
+    HIP_TRY(hipMemsetAsync(m->p.seg_dirty, 0, (size_t)(m->lay.slots >> m->p.S), m->stream));
     return TSX_HIP_OK;
 }
 
@@ -344,10 +357,10 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     hipEvent_t *ev = nullptr;
     if (m->timing) {
-        if (m->ev_used + 3 > m->ev.size()) {
-            for (int i = 0; i < 3; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
+        if (m->ev_used + 4 > m->ev.size()) {
+            for (int i = 0; i < 4; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
         }
-        ev = &m->ev[m->ev_used]; m->ev_used += 3;
+        ev = &m->ev[m->ev_used]; m->ev_used += 4;
         HIP_TRY(hipEventRecord(ev[0], st));
     }
     const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
@@ -356,10 +369,96 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     const size_t lut_bytes = m->lut.size() * 8;
     const int g3 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3);
-    DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
-                                      own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
+
+    // Which insert path?  The partitioned path rewrites every touched segment
+    // once (2 x table bytes at worst), the atomic path pays ~60 ps per k-mer.
+    const TableParams &p = m->p;
+    const int nsegbits = p.l - p.S;
+    const bool can_part = (p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 18);
+    const bool use_part = can_part && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes));
+    if (!use_part) {
+        DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
+                                          own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg,
+                                          (uint64_t *)nullptr, (uint64_t)0, (unsigned long long *)nullptr));
+        HIP_TRY(hipGetLastError());
+        if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
+        return TSX_HIP_OK;
+    }
+
+    const uint64_t maxrec = own_end / 2 + 65536;
+    const uint32_t nseg = 1u << nsegbits;
+    const int b1 = (nsegbits <= 9) ? nsegbits : (nsegbits + 1) / 2, b2 = nsegbits - b1;
+    const uint32_t nb1 = 1u << b1, nb2 = 1u << b2;
+    auto even = [](uint64_t v) { return (v + 1) & ~1ULL; };
+    const uint64_t log_cap = even(maxrec / g3 + maxrec / g3 / 3 + 2048);
+    const uint64_t cap_seg = even(maxrec / nseg + maxrec / nseg / 4 + 512);
+    const uint64_t cap1 = b2 ? even(maxrec / nb1 + maxrec / nb1 / 4 + 4096) : cap_seg;
+    // buffer 0: key log, later the segment lists of a two-level split; buffer 1: level-1 lists
+    const size_t need0 = std::max<uint64_t>((uint64_t)g3 * log_cap, b2 ? (uint64_t)nseg * cap_seg : 0) * 8;
+    const size_t need1 = (uint64_t)nb1 * cap1 * 8;
+    const size_t need[2] = {need0, need1};
+    for (int i = 0; i < 2; ++i)
+        if (need[i] > m->buf_bytes[i]) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (m->d_buf[i]) HIP_TRY(hipFree(m->d_buf[i]));
+            m->d_buf[i] = nullptr; m->buf_bytes[i] = 0;
+            HIP_TRY(hipMalloc((void **)&m->d_buf[i], need[i] + need[i] / 8));
+            m->buf_bytes[i] = need[i] + need[i] / 8;
+        }
+    const size_t cnt_need = (size_t)g3 + nb1 + nseg;
+    if (cnt_need > m->cnt_entries) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (m->d_cnt) HIP_TRY(hipFree(m->d_cnt));
+        m->d_cnt = nullptr; m->cnt_entries = 0;
+        HIP_TRY(hipMalloc((void **)&m->d_cnt, (cnt_need + 1024) * sizeof(unsigned long long)));
+        m->cnt_entries = cnt_need + 1024;
+    }
+    unsigned long long *c_log = m->d_cnt, *c_l1 = m->d_cnt + g3, *c_seg = m->d_cnt + g3 + nb1;
+    HIP_TRY(hipMemsetAsync(m->d_cnt, 0, cnt_need * sizeof(unsigned long long), st));
+
+    hipLaunchKernelGGL((count_fastq_kernel<1>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n, own_end,
+                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], log_cap, c_log);
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+
+    auto stage_cap = [](uint32_t nb) { return nb >= 512 ? 16u : 24u; };
+    auto part_lds = [&](uint32_t nb) { return (size_t)nb * stage_cap(nb) * 8 + (size_t)nb * 16; };
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
+        attr_done = true;
+    }
+    const uint64_t *lists; const unsigned long long *lists_cnt;
+    {   // level 1: log regions -> nb1 lists keyed by the top b1 bits of the home slot
+        const uint32_t cpr = (uint32_t)std::max<int>(1, (m->cus * 6) / g3);
+        hipLaunchKernelGGL(partition_kernel, dim3((uint32_t)g3 * cpr), dim3(PART_NT), part_lds(nb1), st, m->p,
+                           (const uint64_t *)m->d_buf[0], (const unsigned long long *)c_log, log_cap, (uint32_t)g3, cpr,
+                           m->d_buf[1], b2 ? c_l1 : c_seg, cap1, nb1, (uint32_t)(p.l - b1), 0, stage_cap(nb1), m->dbg);
+        HIP_TRY(hipGetLastError());
+        lists = m->d_buf[1]; lists_cnt = b2 ? c_l1 : c_seg;
+    }
+    if (b2) {  // level 2: each level-1 list -> nb2 segment lists
+        const uint32_t cpr = (uint32_t)std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / nb1);
+        hipLaunchKernelGGL(partition_kernel, dim3(nb1 * cpr), dim3(PART_NT), part_lds(nb2), st, m->p,
+                           (const uint64_t *)m->d_buf[1], (const unsigned long long *)c_l1, cap1, nb1, cpr,
+                           m->d_buf[0], c_seg, cap_seg, nb2, (uint32_t)p.S, 1, stage_cap(nb2), m->dbg);
+        HIP_TRY(hipGetLastError());
+        lists = m->d_buf[0]; lists_cnt = c_seg;
+    }
+    {
+        const int gb = (int)std::min<uint32_t>(nseg, (uint32_t)m->cus * 4);
+        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_cnt,
+                           b2 ? cap_seg : cap1, nseg, m->dbg);
+        HIP_TRY(hipGetLastError());
+    }
+    if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_set_path(tsx_hip_map *m, int path) {
+    if (!m || path < 0 || path > 2) return TSX_HIP_EINVAL;
+    m->path = path;
     return TSX_HIP_OK;
 }
 
@@ -370,30 +469,54 @@ extern "C" int tsx_hip_set_timing(tsx_hip_map *m, int enable) {
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *scan_ms, double *count_ms, uint64_t *launches) {
+extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
+                                  uint64_t *launches) {
     if (!m) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
-    double a = 0, b = 0;
-    for (size_t i = 0; i + 3 <= m->ev_used; i += 3) {
-        HIP_TRY(hipEventSynchronize(m->ev[i + 2]));
-        float t1 = 0, t2 = 0;
+    double a = 0, b = 0, c = 0;
+    for (size_t i = 0; i + 4 <= m->ev_used; i += 4) {
+        HIP_TRY(hipEventSynchronize(m->ev[i + 3]));
+        float t1 = 0, t2 = 0, t3 = 0;
         HIP_TRY(hipEventElapsedTime(&t1, m->ev[i], m->ev[i + 1]));
         HIP_TRY(hipEventElapsedTime(&t2, m->ev[i + 1], m->ev[i + 2]));
-        a += t1; b += t2;
+        HIP_TRY(hipEventElapsedTime(&t3, m->ev[i + 2], m->ev[i + 3]));
+        a += t1; b += t2; c += t3;
     }
-    if (scan_ms) *scan_ms = a;
+    if (line_ms) *line_ms = a;
     if (count_ms) *count_ms = b;
-    if (launches) *launches = m->ev_used / 3;
+    if (build_ms) *build_ms = c;
+    if (launches) *launches = m->ev_used / 4;
     m->ev_used = 0;
     return TSX_HIP_OK;
 }
+
+// Device texts are processed in windows so that the partition scratch (about
+// 10 bytes per text byte) stays bounded; windows overlap by the k-1 byte halo
+// exactly like the host pieces.
+static const size_t DEV_WINDOW = (size_t)4 << 30;
 
 extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream) {
     if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15)) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
     HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
-    return run_fastq_piece(m, (const uint8_t *)dev_text, n, n, 0, st);
+    const uint8_t *base = (const uint8_t *)dev_text;
+    const size_t halo = (size_t)m->p.k - 1;
+    for (size_t off = 0; off < n || off == 0; off += DEV_WINDOW) {
+        const size_t own = std::min(DEV_WINDOW, n - off);
+        const size_t len = std::min(own + halo, n - off);
+        int head_open = 0;
+        if (off > 0) {  // does the previous window end inside a line?
+            uint8_t prev = 0;
+            HIP_TRY(hipMemcpyAsync(&prev, base + off - 1, 1, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            head_open = (prev != (uint8_t)'\n') ? 1 : 0;
+        }
+        int rc = run_fastq_piece(m, base + off, len, own, head_open, st);
+        if (rc != TSX_HIP_OK) return rc;
+        if (n == 0) break;
+    }
+    return TSX_HIP_OK;
 }
 
 static int ensure_staging(tsx_hip_map *m) {
