@@ -8,7 +8,7 @@ f=glob.glob('gpurun_out/profq/*/*_kernel_stats.csv')[0]
 for r in csv.DictReader(open(f)):
     print(r['Name'][:45].ljust(46), r['Calls'], 'avg_ms=%.3f'%(float(r['AverageNs'])/1e6), r['Percentage'])
 f=glob.glob('gpurun_out/profq/*/*_kernel_trace.csv')[0]
-rows=[r for r in csv.DictReader(open(f)) if 'partition_kernel' in r['Kernel_Name']]
+rows=[r for r in csv.DictReader(open(f)) if 'partition' in r['Kernel_Name']]
 print('partition calls ms', [round((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6,2) for r in rows])
 for l in open('gpurun_out/profq/bench.log'):
     if l.startswith('{'):

@@ -155,7 +155,8 @@ template <int WK>
 __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableParams p, const uint8_t *buf, uint64_t n,
                                                          uint64_t own_end, int head_open,
                                                          const uint32_t *tile_line, uint64_t ntiles, int dbg,
-                                                         uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt) {
+                                                         uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt,
+                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift) {
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
     __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
     __shared__ uint64_t s_le[TILE / 64];
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hist[256];  // level-1 bucket sizes of this workgroup's log region (nb1 <= 256)
     extern __shared__ uint64_t s_lut[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
     for (int i = tid; i < DSLOTS; i += NT) { s_dpos[i] = 0; s_dcnt[i] = 0; }
     if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
+    for (int i = tid; i < 256; i += NT) s_hist[i] = 0;
     if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
     if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
     unsigned long long added = 0;
@@ -324,8 +327,12 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                     const unsigned long long mk = __ballot(direct_cnt[j] == 1);
                     if (direct_cnt[j] == 1) {
                         const uint32_t at = off + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
-                        if (at < log_cap) my_log[at] = hk[j][0];
-                        else if (!(dbg & 1)) insert_key<WK>(p, hk[j], 1);  // region full: atomic path
+                        if (at < log_cap) {
+                            my_log[at] = hk[j][0];
+                            if (hist) atomicAdd(&s_hist[(uint32_t)(hk[j][0] >> hist_shift) & (hist_nb - 1)], 1u);
+                        } else if (!(dbg & 1)) {
+                            insert_key<WK>(p, hk[j], 1);  // region full: atomic path
+                        }
                     }
                     off += (uint32_t)__builtin_popcountll(mk);
                 }
@@ -343,7 +350,11 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     }
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
     if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
-    if (log_cnt && tid == 0) log_cnt[blockIdx.x] = log_fill;
+    if (log_cnt && tid == 0) log_cnt[blockIdx.x] = min((uint64_t)log_fill, log_cap);
+    if (hist) {
+        __syncthreads();
+        for (uint32_t b = tid; b < hist_nb; b += NT) hist[(size_t)b * gridDim.x + blockIdx.x] = s_hist[b];
+    }
 }
 
 // addKmer for encoded k-mers already on the device (API batches, merge inserts).

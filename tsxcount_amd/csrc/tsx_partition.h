@@ -60,7 +60,7 @@ __global__ __launch_bounds__(PART_NT) void partition_kernel(TableParams p, const
             const uint32_t have = min(s_cnt[b], cap);
             const uint32_t nout = all ? have : (have & ~(uint32_t)(PART_FLUSH - 1));
             s_out[b] = nout;
-            if (nout) s_at[b] = atomicAdd(&dst_cnt[list0 + b], (unsigned long long)nout);
+            if (nout) s_at[b] = (dbg & 128) ? 0ULL : atomicAdd(&dst_cnt[list0 + b], (unsigned long long)nout);
         }
         __syncthreads();
         const uint32_t oct = tid >> 3, ol = tid & 7;
@@ -129,19 +129,151 @@ __global__ __launch_bounds__(PART_NT) void partition_kernel(TableParams p, const
     flush(true);
 }
 
+// Atomic-free radix level: ONE workgroup owns a whole source region, so the write
+// cursors of its destination lists live in LDS.  Two uses:
+//   level 1  region = one workgroup's key log; cursor[b] starts at the exact offset
+//            offs[b * nregions + r] that offsets_kernel derived from the scan
+//            kernel's per-workgroup histograms: the output is a packed array, no
+//            capacity to overflow, no global atomic at all
+//   level 2  region = one level-1 bucket (start/count from offsets_kernel); list
+//            (r * nb + b) has room for dst_cap keys, cursor starts at 0 and its
+//            final value is published to dst_cnt
+// Returning atomics on shared list cursors cost 12 of 17 ms in the first version.
+__global__ void partition_private_kernel(TableParams p, const uint64_t *src, const unsigned long long *src_start,
+                                         const unsigned long long *src_cnt, uint64_t src_cap, uint32_t nregions,
+                                         uint64_t *dst, const unsigned long long *offs, unsigned long long *dst_cnt,
+                                         uint64_t dst_cap, uint32_t nb, uint32_t shift, uint32_t cap) {
+    extern __shared__ uint64_t s_part[];  // nb * cap staged keys | nb cursors | nb limits | nb counts
+    uint64_t *s_stage = s_part;
+    unsigned long long *s_cur = reinterpret_cast<unsigned long long *>(s_part + (size_t)nb * cap);
+    unsigned long long *s_lim = s_cur + nb;
+    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_lim + nb);
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+        __syncthreads();
+        for (uint32_t b = tid; b < nb; b += nt) {
+            s_cnt[b] = 0;
+            if (offs) { s_cur[b] = offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
+            else { s_cur[b] = ((uint64_t)r * nb + b) * dst_cap; s_lim[b] = s_cur[b] + dst_cap; }
+        }
+        __syncthreads();
+        const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);
+        const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
+        const uint64_t batch = (uint64_t)nt * PART_RPT;
+
+        auto flush = [&](bool all) {
+            const uint32_t oct = tid >> 3, ol = tid & 7;
+            for (uint32_t b = oct; b < nb; b += nt / 8) {
+                const uint32_t have = min(s_cnt[b], cap);
+                const uint32_t nout = all ? have : (have & ~(uint32_t)(PART_FLUSH - 1));
+                if (nout == 0) continue;                   // uniform inside the octet
+                const unsigned long long at = s_cur[b], lim = s_lim[b];
+                uint64_t *st = s_stage + (size_t)b * cap;
+                for (uint32_t q = ol; q < nout; q += 8) {
+                    const uint64_t key = st[q];
+                    if (at + q < lim) dst[at + q] = key;
+                    else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }  // list full: atomic path
+                }
+                // at most 7 staged keys stay behind (none after a full flush): move them to the front
+                const uint32_t qs = nout + ol;
+                const uint64_t keep = (qs < have) ? st[qs] : 0;
+                if (qs < have) st[ol] = keep;
+                if (ol == 0) { s_cnt[b] = have - nout; s_cur[b] = at + nout; }
+            }
+        };
+
+        uint64_t cur[PART_RPT], nxt[PART_RPT];
+#pragma unroll
+        for (int q = 0; q < PART_RPT; ++q) {
+            const uint64_t i = (uint64_t)q * nt + tid;
+            cur[q] = (i < n) ? in[i] : 0;
+        }
+        for (uint64_t base = 0; base < n; base += batch) {
+#pragma unroll
+            for (int q = 0; q < PART_RPT; ++q) {
+                const uint64_t i = base + batch + (uint64_t)q * nt + tid;
+                nxt[q] = (i < n) ? in[i] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < PART_RPT; ++q) {
+                const uint64_t i = base + (uint64_t)q * nt + tid;
+                if (i < n) {
+                    const uint64_t key = cur[q];
+                    const uint32_t b = (uint32_t)(key >> shift) & (nb - 1);
+                    const uint32_t slot = atomicAdd(&s_cnt[b], 1u);
+                    if (slot < cap) {
+                        s_stage[(size_t)b * cap + slot] = key;
+                    } else {  // staging burst: take the next place of the list directly
+                        const unsigned long long at = atomicAdd(&s_cur[b], 1ULL);
+                        if (at < s_lim[b]) dst[at] = key;
+                        else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }
+                    }
+                }
+            }
+            __syncthreads();
+            flush(false);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < PART_RPT; ++q) cur[q] = nxt[q];
+        }
+        flush(true);
+        __syncthreads();
+        if (dst_cnt)
+            for (uint32_t b = tid; b < nb; b += nt)
+                dst_cnt[(size_t)r * nb + b] = min(s_cur[b], s_lim[b]) - ((uint64_t)r * nb + b) * dst_cap;
+    }
+}
+
+// Exclusive scan of the per-workgroup level-1 histograms hist[b * G + g]
+// (bucket-major) into write offsets, plus start and size of every bucket.
+__global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *hist, unsigned long long *offs, uint32_t nb,
+                                                       uint32_t G, unsigned long long *bucket_start,
+                                                       unsigned long long *bucket_cnt) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_base;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t total = (uint64_t)nb * G;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (uint64_t start = 0; start < total; start += 1024) {
+        const uint64_t i = start + tid;
+        const unsigned long long v = (i < total) ? hist[i] : 0;
+        const unsigned long long inc = wave_incl_scan(v);
+        if ((tid & 63) == 63) s_w[tid >> 6] = inc;
+        __syncthreads();
+        unsigned long long woff = 0;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) woff += s_w[w];
+        const unsigned long long base = s_base;
+        const unsigned long long excl = base + woff + inc - v;
+        if (i < total) {
+            offs[i] = excl;
+            if (i % G == 0) bucket_start[i / G] = excl;
+        }
+        __syncthreads();
+        if (tid == 1023) s_base = base + woff + inc;
+        __syncthreads();
+    }
+    // sizes: start[b+1] - start[b]
+    __syncthreads();
+    const unsigned long long grand = s_base;
+    for (uint32_t b = tid; b < nb; b += 1024)
+        bucket_cnt[b] = ((b + 1 < nb) ? bucket_start[b + 1] : grand) - bucket_start[b];
+}
+
 // One workgroup builds one segment: slots [seg << S, (seg+1) << S) live in LDS
 // while the segment's key list is inserted with LDS atomics (same slot format,
 // same probe sequence as insert_key), then go back to HBM in one sweep.
 // Segments that already hold data (seg_dirty) are loaded first; untouched
 // segments with an empty list are skipped.
 __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, const uint64_t *lists,
+                                                              const unsigned long long *list_start,
                                                               const unsigned long long *list_cnt,
                                                               uint64_t list_cap, uint32_t nseg, int dbg) {
     extern __shared__ uint64_t s_seg[];  // 2^S slots
     const uint32_t nslots = 1u << p.S;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint64_t n = min((uint64_t)list_cnt[seg], list_cap);
+        const uint64_t n = list_start ? (uint64_t)list_cnt[seg] : min((uint64_t)list_cnt[seg], list_cap);
         if (n == 0) continue;
         uint64_t *slots = p.table + ((uint64_t)seg << p.S);
         const bool dirty = p.seg_dirty[seg] != 0;
@@ -154,64 +286,45 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
                 *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        const uint64_t *in = lists + (uint64_t)seg * list_cap;
+        const uint64_t *in = lists + (list_start ? (uint64_t)list_start[seg] : (uint64_t)seg * list_cap);
         const uint64_t one = 1ULL << p.cshift;
-        // keys are fetched BUILD_UNROLL at a time before any of them is inserted, so the
-        // HBM latency is paid once per group instead of once per key
-        constexpr int BUILD_UNROLL = 8;
-        for (uint64_t r0 = 0; r0 < n; r0 += (uint64_t)nt * BUILD_UNROLL) {
-            uint64_t keys[BUILD_UNROLL];
-#pragma unroll
-            for (int u = 0; u < BUILD_UNROLL; ++u) {
-                const uint64_t r = r0 + (uint64_t)u * nt + tid;
-                keys[u] = (r < n) ? ((dbg & 32) ? (r * 0x9E3779B97F4A7C15ULL) : in[r]) : 0;
+        // Every lane streams its own keys (tid, tid+nt, ...): one probe per loop round,
+        // and a lane that has placed its key moves straight on to its next one, so the
+        // wave stays full until the lists run dry instead of idling on its longest probe
+        // chain.  Three keys per lane are always in flight from HBM.
+        uint64_t r = tid;
+        uint64_t cur = (r < n) ? in[r] : 0;
+        uint64_t f1 = (r + nt < n) ? in[r + nt] : 0;
+        uint64_t f2 = (r + 2ULL * nt < n) ? in[r + 2ULL * nt] : 0;
+        uint64_t f3 = (r + 3ULL * nt < n) ? in[r + 3ULL * nt] : 0;
+        bool live = (r < n) && !(dbg & 2);
+        uint32_t i = 1;
+        while (live) {
+            const uint32_t q0 = (uint32_t)(cur & p.seg_mask);
+            const uint64_t key0 = (((cur >> p.l) << p.R) & p.k0mask) | i;  // split_key for WK = 1
+            const uint32_t q = (q0 + ((i * (i + 1)) >> 1)) & (uint32_t)p.seg_mask;
+            const unsigned long long old =
+                atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
+            bool placed = (old == 0ULL);
+            if (!placed && (old & p.k0mask) == key0) {
+                const unsigned long long prev =
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[q]), (unsigned long long)one);
+                const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
+                if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
+                placed = true;
             }
-            // All BUILD_UNROLL probe chains of a thread advance together: one round issues
-            // up to 8 independent LDS CAS, so a round costs one LDS round trip, and the
-            // number of rounds is the longest chain in the wave, not the sum over keys.
-            uint32_t q0v[BUILD_UNROLL], iv[BUILD_UNROLL];
-            uint64_t e0v[BUILD_UNROLL];
-            uint32_t live = 0;
-#pragma unroll
-            for (int u = 0; u < BUILD_UNROLL; ++u) {
-                const uint64_t r = r0 + (uint64_t)u * nt + tid;
-                q0v[u] = (uint32_t)(keys[u] & p.seg_mask);
-                e0v[u] = ((keys[u] >> p.l) << p.R) & p.k0mask;  // split_key for WK = 1
-                iv[u] = 1;
-                if (r < n && !(dbg & 2)) live |= 1u << u;
+            if (!placed && i + 1 > p.max_reprobes) {
+                atomicAdd(&p.stats[ST_FAIL], 1ULL);
+                placed = true;
             }
-            while (live) {
-                unsigned long long oldv[BUILD_UNROLL];
-                uint32_t qv[BUILD_UNROLL];
-#pragma unroll
-                for (int u = 0; u < BUILD_UNROLL; ++u) {  // issue: up to 8 CAS in flight
-                    const uint32_t i = iv[u];
-                    qv[u] = (q0v[u] + ((i * (i + 1)) >> 1)) & (uint32_t)p.seg_mask;
-                    oldv[u] = 1;
-                    if (live & (1u << u))
-                        oldv[u] = atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[qv[u]]), 0ULL,
-                                            (unsigned long long)(e0v[u] | i | one));
-                }
-#pragma unroll
-                for (int u = 0; u < BUILD_UNROLL; ++u) {  // resolve
-                    if (!(live & (1u << u))) continue;
-                    const uint32_t i = iv[u];
-                    const uint64_t key0 = e0v[u] | i;
-                    if (oldv[u] == 0ULL) {
-                        live &= ~(1u << u);
-                    } else if ((oldv[u] & p.k0mask) == key0) {
-                        const unsigned long long prev =
-                            atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[qv[u]]), (unsigned long long)one);
-                        const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
-                        if (carry) sec_add(p, ((uint64_t)seg << p.S) | qv[u], carry);
-                        live &= ~(1u << u);
-                    } else if (i + 1 > p.max_reprobes) {
-                        atomicAdd(&p.stats[ST_FAIL], 1ULL);
-                        live &= ~(1u << u);
-                    } else {
-                        iv[u] = i + 1;
-                    }
-                }
+            if (placed) {
+                r += nt;
+                live = r < n;
+                cur = f1; f1 = f2; f2 = f3;
+                f3 = (r + 3ULL * nt < n) ? in[r + 3ULL * nt] : 0;
+                i = 1;
+            } else {
+                ++i;
             }
         }
         __syncthreads();

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -374,12 +375,13 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     // once (2 x table bytes at worst), the atomic path pays ~60 ps per k-mer.
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
-    const bool can_part = (p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 18);
+    const bool can_part = (p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 17);
     const bool use_part = can_part && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes));
     if (!use_part) {
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
                                           own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg,
-                                          (uint64_t *)nullptr, (uint64_t)0, (unsigned long long *)nullptr));
+                                          (uint64_t *)nullptr, (uint64_t)0, (unsigned long long *)nullptr,
+                                          (uint32_t *)nullptr, 0u, 0u));
         HIP_TRY(hipGetLastError());
         if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
         return TSX_HIP_OK;
@@ -387,15 +389,15 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
 
     const uint64_t maxrec = own_end / 2 + 65536;
     const uint32_t nseg = 1u << nsegbits;
-    const int b1 = (nsegbits <= 9) ? nsegbits : (nsegbits + 1) / 2, b2 = nsegbits - b1;
+    // level-1 fan-out is capped at 256 (the scan kernel keeps that histogram in LDS)
+    const int b1 = std::min(8, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2), b2 = nsegbits - b1;
     const uint32_t nb1 = 1u << b1, nb2 = 1u << b2;
     auto even = [](uint64_t v) { return (v + 1) & ~1ULL; };
     const uint64_t log_cap = even(maxrec / g3 + maxrec / g3 / 3 + 2048);
     const uint64_t cap_seg = even(maxrec / nseg + maxrec / nseg / 4 + 512);
-    const uint64_t cap1 = b2 ? even(maxrec / nb1 + maxrec / nb1 / 4 + 4096) : cap_seg;
     // buffer 0: key log, later the segment lists of a two-level split; buffer 1: level-1 lists
     const size_t need0 = std::max<uint64_t>((uint64_t)g3 * log_cap, b2 ? (uint64_t)nseg * cap_seg : 0) * 8;
-    const size_t need1 = (uint64_t)nb1 * cap1 * 8;
+    const size_t need1 = (uint64_t)g3 * log_cap * 8;  // packed level-1 output: never more keys than the log
     const size_t need[2] = {need0, need1};
     for (int i = 0; i < 2; ++i)
         if (need[i] > m->buf_bytes[i]) {
@@ -405,51 +407,68 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             HIP_TRY(hipMalloc((void **)&m->d_buf[i], need[i] + need[i] / 8));
             m->buf_bytes[i] = need[i] + need[i] / 8;
         }
-    const size_t cnt_need = (size_t)g3 + nb1 + nseg;
-    if (cnt_need > m->cnt_entries) {
+    // counters: [log fill per workgroup | level-1 bucket start | level-1 bucket size | segment list size]
+    // then the level-1 histogram matrix (u32) and its exclusive scan (u64), both nb1 x g3
+    const size_t cnt_need = (size_t)g3 + 2 * (size_t)nb1 + nseg;
+    const size_t mat = (size_t)nb1 * g3;
+    const size_t cnt_bytes = cnt_need * 8 + mat * 8 + mat * 4 + 64;
+    if (cnt_bytes > m->cnt_entries) {
         HIP_TRY(hipStreamSynchronize(st));
         if (m->d_cnt) HIP_TRY(hipFree(m->d_cnt));
         m->d_cnt = nullptr; m->cnt_entries = 0;
-        HIP_TRY(hipMalloc((void **)&m->d_cnt, (cnt_need + 1024) * sizeof(unsigned long long)));
-        m->cnt_entries = cnt_need + 1024;
+        HIP_TRY(hipMalloc((void **)&m->d_cnt, cnt_bytes + 4096));
+        m->cnt_entries = cnt_bytes + 4096;
     }
-    unsigned long long *c_log = m->d_cnt, *c_l1 = m->d_cnt + g3, *c_seg = m->d_cnt + g3 + nb1;
-    HIP_TRY(hipMemsetAsync(m->d_cnt, 0, cnt_need * sizeof(unsigned long long), st));
+    unsigned long long *c_log = m->d_cnt, *c_bstart = c_log + g3, *c_bcnt = c_bstart + nb1, *c_seg = c_bcnt + nb1;
+    unsigned long long *d_offs = c_seg + nseg;
+    uint32_t *d_hist = reinterpret_cast<uint32_t *>(d_offs + mat);
+    HIP_TRY(hipMemsetAsync(m->d_cnt, 0, cnt_need * 8, st));
 
     hipLaunchKernelGGL((count_fastq_kernel<1>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n, own_end,
-                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], log_cap, c_log);
+                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], log_cap, c_log, d_hist, nb1,
+                       (uint32_t)(p.l - b1));
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[2], st));
 
-    auto stage_cap = [](uint32_t nb) { return nb >= 512 ? 16u : 24u; };
-    auto part_lds = [&](uint32_t nb) { return (size_t)nb * stage_cap(nb) * 8 + (size_t)nb * 16; };
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_private_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
         attr_done = true;
     }
-    const uint64_t *lists; const unsigned long long *lists_cnt;
-    {   // level 1: log regions -> nb1 lists keyed by the top b1 bits of the home slot
-        const uint32_t cpr = (uint32_t)std::max<int>(1, (m->cus * 6) / g3);
-        hipLaunchKernelGGL(partition_kernel, dim3((uint32_t)g3 * cpr), dim3(PART_NT), part_lds(nb1), st, m->p,
-                           (const uint64_t *)m->d_buf[0], (const unsigned long long *)c_log, log_cap, (uint32_t)g3, cpr,
-                           m->d_buf[1], b2 ? c_l1 : c_seg, cap1, nb1, (uint32_t)(p.l - b1), 0, stage_cap(nb1), m->dbg);
+    auto part_lds = [](uint32_t nb, uint32_t cap) { return (size_t)nb * ((size_t)cap * 8 + 20); };
+    // staging depth: 7 keys may stay behind a flush, plus a batch's arrivals (Poisson, mean = batch / nb)
+    auto stage_cap = [](uint32_t threads, uint32_t nb) {
+        const uint32_t mean = std::max<uint32_t>(1, threads * PART_RPT / nb);
+        return std::min<uint32_t>(64, 8 + mean + 6 * (uint32_t)std::ceil(std::sqrt((double)mean)) + 4);
+    };
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)d_hist, d_offs, nb1, (uint32_t)g3,
+                       c_bstart, c_bcnt);
+    {   // level 1: every workgroup's key log -> packed array ordered by the top b1 bits of the home slot
+        const uint32_t cap = stage_cap(PART_NT, nb1);
+        hipLaunchKernelGGL(partition_private_kernel, dim3(g3), dim3(PART_NT), part_lds(nb1, cap), st, m->p,
+                           (const uint64_t *)m->d_buf[0], (const unsigned long long *)nullptr,
+                           (const unsigned long long *)c_log, log_cap, (uint32_t)g3, m->d_buf[1],
+                           (const unsigned long long *)d_offs, (unsigned long long *)nullptr, (uint64_t)0, nb1,
+                           (uint32_t)(p.l - b1), cap);
         HIP_TRY(hipGetLastError());
-        lists = m->d_buf[1]; lists_cnt = b2 ? c_l1 : c_seg;
     }
-    if (b2) {  // level 2: each level-1 list -> nb2 segment lists
-        const uint32_t cpr = (uint32_t)std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / nb1);
-        hipLaunchKernelGGL(partition_kernel, dim3(nb1 * cpr), dim3(PART_NT), part_lds(nb2), st, m->p,
-                           (const uint64_t *)m->d_buf[1], (const unsigned long long *)c_l1, cap1, nb1, cpr,
-                           m->d_buf[0], c_seg, cap_seg, nb2, (uint32_t)p.S, 1, stage_cap(nb2), m->dbg);
+    const uint64_t *lists = m->d_buf[1];
+    const unsigned long long *lists_start = c_bstart, *lists_cnt = c_bcnt;
+    uint64_t lists_cap = 0;
+    if (b2) {  // level 2: one workgroup per level-1 bucket -> nb2 segment lists each
+        const uint32_t thr = 1024, cap = stage_cap(thr, nb2);
+        hipLaunchKernelGGL(partition_private_kernel, dim3(nb1), dim3(thr), part_lds(nb2, cap), st, m->p,
+                           (const uint64_t *)m->d_buf[1], (const unsigned long long *)c_bstart,
+                           (const unsigned long long *)c_bcnt, (uint64_t)0, nb1, m->d_buf[0],
+                           (const unsigned long long *)nullptr, c_seg, cap_seg, nb2, (uint32_t)p.S, cap);
         HIP_TRY(hipGetLastError());
-        lists = m->d_buf[0]; lists_cnt = c_seg;
+        lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = c_seg; lists_cap = cap_seg;
     }
-    {
+    if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
         const int gb = (int)std::min<uint32_t>(nseg, (uint32_t)m->cus * 4);
-        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_cnt,
-                           b2 ? cap_seg : cap1, nseg, m->dbg);
+        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_start,
+                           lists_cnt, lists_cap, nseg, m->dbg);
         HIP_TRY(hipGetLastError());
     }
     if (ev) HIP_TRY(hipEventRecord(ev[3], st));
