@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--l", type=int, default=31, help="log2 table slots per GPU")
+    ap.add_argument("--l", type=int, default=30, help="log2 table slots per GPU (load factor 0.75 at the default input)")
     ap.add_argument("--reads", type=int, default=1087000, help="synthetic reads per GPU (~1e9 k-mers at k=31)")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--path", default="auto", choices=["auto", "atomic", "partitioned"])

@@ -53,6 +53,12 @@ struct TableParams {
     uint32_t max_reprobes;
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// every outstanding global load, store and atomic of the wave (s_waitcnt vmcnt(0)),
+// which serialises prefetched loads and fire-and-forget stores with the barrier;
+// the kernels here exchange data between waves through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;

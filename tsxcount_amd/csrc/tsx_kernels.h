@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
-        __syncthreads();  // previous tile's LDS fully consumed
+        lds_barrier();  // previous tile's LDS fully consumed
         {
             const uint64_t off = base + (uint64_t)tid * 16;
             uint32_t nl, le, code;
@@ -205,12 +205,12 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
             const uint32_t c = __popc(le);
             const uint32_t inc = wave_incl_scan(c);
             if (lane == 63) s_wsum[tid >> 6] = inc;
-            __syncthreads();
+            lds_barrier();
             uint32_t woff = tile_line[tile];
             for (int w = 0; w < (tid >> 6); ++w) woff += s_wsum[w];
             s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
         }
-        __syncthreads();
+        lds_barrier();
 
         for (int round = 0; round < TILE / BATCH; ++round) {
             uint64_t hk[PER_THREAD][WK];
@@ -232,6 +232,10 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                 const uint64_t need1 = (k > 64) ? ((k >= 128) ? ~0ULL : ((1ULL << (k - 64)) - 1ULL)) : 0ULL;
                 const bool valid = ((line & 3u) == 1u) && ((m0 & need0) == 0) && ((m1 & need1) == 0) &&
                                    (gpos + k <= n) && (gpos < own_end);
+                slot_of[j] = -1; direct_cnt[j] = 0;
+                // header, '+' and quality lines make up half of a FASTQ text: a wave whose 64
+                // consecutive positions hold no k-mer start skips extraction, hashing and dedup
+                if (__ballot(valid) == 0ULL) continue;
                 uint64_t x[WK];
                 extract_kmer<WK>(s_codes, pp, p.top_mask, x);
                 // run-length merge across the wave: lanes hold consecutive positions
@@ -244,7 +248,6 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                 const unsigned long long above = (lane == 63) ? 0ULL : (bnd >> (lane + 1));
                 const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)(63 - lane)) + 1u;
                 added += valid ? 1ULL : 0ULL;
-                slot_of[j] = -1; direct_cnt[j] = 0;
                 if (leader) {
                     hash_apply<WK>(p, (const uint64_t *)s_lut, x, hk[j]);
                     uint32_t slot = (uint32_t)(mix64(hk[j][0] ^ (WK > 1 ? hk[j][WK - 1] : 0)) >> 40) & (DSLOTS - 1);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // Phase B.  Totals are final now.  Three destinations:
             //   d == 1 and a key log   -> this workgroup's log region (partitioned path)
             //   d  > 1 and a key log   -> the wave's hot cache (flushed once at kernel end)
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                 // one contiguous run of the log region per wave and j: consecutive lanes
                 // write consecutive keys (full 64-B sectors), offsets are scalar arithmetic
                 if (lane == 0) s_wsum[tid >> 6] = wave_emit;
-                __syncthreads();
+                lds_barrier();
                 uint32_t off = log_fill, total = 0;
                 for (int w = 0; w < NT / 64; ++w) {
                     if (w < (tid >> 6)) off += s_wsum[w];
@@ -338,11 +341,11 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                 }
                 log_fill += total;
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
     if (WK == 1 && my_log) {  // flush the hot caches: a handful of atomics per workgroup
-        __syncthreads();
+        lds_barrier();
         if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) {
             const uint64_t h1[WK] = {s_hot_key[tid]};
             insert_key<WK>(p, h1, s_hot_cnt[tid]);
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
     if (log_cnt && tid == 0) log_cnt[blockIdx.x] = min((uint64_t)log_fill, log_cap);
     if (hist) {
-        __syncthreads();
+        lds_barrier();
         for (uint32_t b = tid; b < hist_nb; b += NT) hist[(size_t)b * gridDim.x + blockIdx.x] = s_hist[b];
     }
 }

@@ -129,99 +129,137 @@ __global__ __launch_bounds__(PART_NT) void partition_kernel(TableParams p, const
     flush(true);
 }
 
-// Atomic-free radix level: ONE workgroup owns a whole source region, so the write
-// cursors of its destination lists live in LDS.  Two uses:
-//   level 1  region = one workgroup's key log; cursor[b] starts at the exact offset
-//            offs[b * nregions + r] that offsets_kernel derived from the scan
-//            kernel's per-workgroup histograms: the output is a packed array, no
-//            capacity to overflow, no global atomic at all
-//   level 2  region = one level-1 bucket (start/count from offsets_kernel); list
-//            (r * nb + b) has room for dst_cap keys, cursor starts at 0 and its
-//            final value is published to dst_cnt
-// Returning atomics on shared list cursors cost 12 of 17 ms in the first version.
-__global__ void partition_private_kernel(TableParams p, const uint64_t *src, const unsigned long long *src_start,
-                                         const unsigned long long *src_cnt, uint64_t src_cap, uint32_t nregions,
-                                         uint64_t *dst, const unsigned long long *offs, unsigned long long *dst_cnt,
-                                         uint64_t dst_cap, uint32_t nb, uint32_t shift, uint32_t cap) {
-    extern __shared__ uint64_t s_part[];  // nb * cap staged keys | nb cursors | nb limits | nb counts
+// Atomic-free radix level.  A workgroup (r, c) takes every cpr-th batch of source
+// region r and owns the write cursors of its destination lists, which therefore
+// live in LDS (returning atomics on shared cursors cost 12 of 17 ms in the first
+// version).  Two uses:
+//   level 1  region = one scan workgroup's key log, cpr = 1; cursor[b] starts at the
+//            exact offset offs[b * nregions + r] that offsets_kernel derived from the
+//            scan kernel's histograms: the output is a packed array ordered by bucket
+//   level 2  region = one level-1 bucket (start/count from offsets_kernel); the keys
+//            of segment (r * nb + b) go to sub-list ((r * nb + b) * cpr + c) with
+//            room for dst_cap keys; its final size is published to dst_cnt
+// Staging is a ring of 2^capbits keys per list (no compaction after a flush).
+// A flush is (A) one thread per list: how many keys (multiple of 8 = 64 B) and
+// where; (B) 8 consecutive lanes per list copy them, with the LDS reads of all
+// lists an octet serves issued before the first store.
+constexpr int PART_ITER = 8;  // lists per octet: nb <= PART_ITER * PART_NT / 8 = 256
+__global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
+    TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
+    uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
+    unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift, uint32_t capbits) {
+    extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads
+    const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
-    unsigned long long *s_cur = reinterpret_cast<unsigned long long *>(s_part + (size_t)nb * cap);
+    unsigned long long *s_cur = reinterpret_cast<unsigned long long *>(s_part + ((size_t)nb << capbits));
     unsigned long long *s_lim = s_cur + nb;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_lim + nb);
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
-        __syncthreads();
-        for (uint32_t b = tid; b < nb; b += nt) {
-            s_cnt[b] = 0;
-            if (offs) { s_cur[b] = offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
-            else { s_cur[b] = ((uint64_t)r * nb + b) * dst_cap; s_lim[b] = s_cur[b] + dst_cap; }
+    unsigned long long *s_meta = s_lim + nb;
+    uint32_t *s_tail = reinterpret_cast<uint32_t *>(s_meta + nb);
+    uint32_t *s_head = s_tail + nb;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = blockIdx.x / cpr, c = blockIdx.x % cpr;
+    if (r >= nregions) return;
+    for (uint32_t b = tid; b < nb; b += PART_NT) {
+        s_tail[b] = 0; s_head[b] = 0;
+        if (offs) { s_cur[b] = offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
+        else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap; s_lim[b] = s_cur[b] + dst_cap; }
+    }
+    lds_barrier();
+    const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);
+    const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
+    constexpr uint64_t BATCH_REC = (uint64_t)PART_NT * PART_RPT;
+    const uint64_t stride = (uint64_t)cpr * BATCH_REC;
+
+    auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
+        if (at < lim) dst[at] = key;
+        else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }  // sub-list full: atomic path
+    };
+    auto flush = [&](bool all) {
+        for (uint32_t b = tid; b < nb; b += PART_NT) {  // (A)
+            const uint32_t head = s_head[b];
+            const uint32_t tail = min(s_tail[b], head + CAP);  // arrivals past the ring went out directly
+            const uint32_t avail = tail - head;
+            const uint32_t nout = all ? avail : (avail & ~(uint32_t)(PART_FLUSH - 1));
+            const unsigned long long at = s_cur[b];
+            s_meta[b] = (at << 16) | ((unsigned long long)(head & cmask) << 8) | nout;
+            s_head[b] = head + nout;
+            s_tail[b] = tail;
+            s_cur[b] = at + nout;
         }
-        __syncthreads();
-        const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);
-        const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
-        const uint64_t batch = (uint64_t)nt * PART_RPT;
-
-        auto flush = [&](bool all) {
-            const uint32_t oct = tid >> 3, ol = tid & 7;
-            for (uint32_t b = oct; b < nb; b += nt / 8) {
-                const uint32_t have = min(s_cnt[b], cap);
-                const uint32_t nout = all ? have : (have & ~(uint32_t)(PART_FLUSH - 1));
-                if (nout == 0) continue;                   // uniform inside the octet
-                const unsigned long long at = s_cur[b], lim = s_lim[b];
-                uint64_t *st = s_stage + (size_t)b * cap;
-                for (uint32_t q = ol; q < nout; q += 8) {
-                    const uint64_t key = st[q];
-                    if (at + q < lim) dst[at + q] = key;
-                    else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }  // list full: atomic path
-                }
-                // at most 7 staged keys stay behind (none after a full flush): move them to the front
-                const uint32_t qs = nout + ol;
-                const uint64_t keep = (qs < have) ? st[qs] : 0;
-                if (qs < have) st[ol] = keep;
-                if (ol == 0) { s_cnt[b] = have - nout; s_cur[b] = at + nout; }
+        lds_barrier();
+        const uint32_t oct = tid >> 3, ol = tid & 7;  // (B)
+        unsigned long long meta[PART_ITER], lim[PART_ITER];
+        uint64_t k0[PART_ITER], k1[PART_ITER];
+#pragma unroll
+        for (int u = 0; u < PART_ITER; ++u) {
+            const uint32_t b = oct + u * (PART_NT / 8);
+            meta[u] = (b < nb) ? s_meta[b] : 0ULL;
+            lim[u] = (b < nb) ? s_lim[b] : 0ULL;
+        }
+#pragma unroll
+        for (int u = 0; u < PART_ITER; ++u) {
+            const uint32_t b = oct + u * (PART_NT / 8);
+            const uint32_t nout = (uint32_t)(meta[u] & 0xFF), hd = (uint32_t)(meta[u] >> 8) & 0xFF;
+            const uint64_t *ring = s_stage + ((size_t)b << capbits);
+            k0[u] = (ol < nout) ? ring[(hd + ol) & cmask] : 0;
+            k1[u] = (ol + 8 < nout) ? ring[(hd + ol + 8) & cmask] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PART_ITER; ++u) {
+            const uint32_t nout = (uint32_t)(meta[u] & 0xFF);
+            const unsigned long long at = meta[u] >> 16;
+            if (ol < nout) put(k0[u], at + ol, lim[u]);
+            if (ol + 8 < nout) put(k1[u], at + ol + 8, lim[u]);
+            if (nout > 16) {  // only rings deeper than 16 or the final flush get here
+                const uint32_t b = oct + u * (PART_NT / 8);
+                const uint32_t hd = (uint32_t)(meta[u] >> 8) & 0xFF;
+                const uint64_t *ring = s_stage + ((size_t)b << capbits);
+                for (uint32_t q = ol + 16; q < nout; q += 8) put(ring[(hd + q) & cmask], at + q, lim[u]);
             }
-        };
+        }
+    };
 
-        uint64_t cur[PART_RPT], nxt[PART_RPT];
+    uint64_t cur[PART_RPT], nxt[PART_RPT];
+    uint64_t base = (uint64_t)c * BATCH_REC;
+#pragma unroll
+    for (int q = 0; q < PART_RPT; ++q) {
+        const uint64_t i = base + (uint64_t)q * PART_NT + tid;
+        cur[q] = (i < n) ? in[i] : 0;
+    }
+    for (; base < n; base += stride) {
 #pragma unroll
         for (int q = 0; q < PART_RPT; ++q) {
-            const uint64_t i = (uint64_t)q * nt + tid;
-            cur[q] = (i < n) ? in[i] : 0;
+            const uint64_t i = base + stride + (uint64_t)q * PART_NT + tid;
+            nxt[q] = (i < n) ? in[i] : 0;
         }
-        for (uint64_t base = 0; base < n; base += batch) {
 #pragma unroll
-            for (int q = 0; q < PART_RPT; ++q) {
-                const uint64_t i = base + batch + (uint64_t)q * nt + tid;
-                nxt[q] = (i < n) ? in[i] : 0;
-            }
-#pragma unroll
-            for (int q = 0; q < PART_RPT; ++q) {
-                const uint64_t i = base + (uint64_t)q * nt + tid;
-                if (i < n) {
-                    const uint64_t key = cur[q];
-                    const uint32_t b = (uint32_t)(key >> shift) & (nb - 1);
-                    const uint32_t slot = atomicAdd(&s_cnt[b], 1u);
-                    if (slot < cap) {
-                        s_stage[(size_t)b * cap + slot] = key;
-                    } else {  // staging burst: take the next place of the list directly
-                        const unsigned long long at = atomicAdd(&s_cur[b], 1ULL);
-                        if (at < s_lim[b]) dst[at] = key;
-                        else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }
-                    }
+        for (int q = 0; q < PART_RPT; ++q) {
+            const uint64_t i = base + (uint64_t)q * PART_NT + tid;
+            if (i < n) {
+                const uint64_t key = cur[q];
+                const uint32_t b = (uint32_t)(key >> shift) & (nb - 1);
+                const uint32_t slot = atomicAdd(&s_tail[b], 1u);
+                if (slot - s_head[b] < CAP) {
+                    s_stage[((size_t)b << capbits) + (slot & cmask)] = key;
+                } else {  // ring full: take the next place of the list directly
+                    const unsigned long long at = atomicAdd(&s_cur[b], 1ULL);
+                    put(key, at, s_lim[b]);
                 }
             }
-            __syncthreads();
-            flush(false);
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < PART_RPT; ++q) cur[q] = nxt[q];
         }
-        flush(true);
-        __syncthreads();
-        if (dst_cnt)
-            for (uint32_t b = tid; b < nb; b += nt)
-                dst_cnt[(size_t)r * nb + b] = min(s_cur[b], s_lim[b]) - ((uint64_t)r * nb + b) * dst_cap;
+        lds_barrier();
+        flush(false);
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < PART_RPT; ++q) cur[q] = nxt[q];
     }
+    flush(true);
+    lds_barrier();
+    if (dst_cnt)
+        for (uint32_t b = tid; b < nb; b += PART_NT) {
+            const uint64_t li = ((uint64_t)r * nb + b) * cpr + c;
+            dst_cnt[li] = min(s_cur[b], s_lim[b]) - li * dst_cap;
+        }
 }
 
 // Exclusive scan of the per-workgroup level-1 histograms hist[b * G + g]
@@ -268,16 +306,34 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *hist, uns
 __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, const uint64_t *lists,
                                                               const unsigned long long *list_start,
                                                               const unsigned long long *list_cnt,
-                                                              uint64_t list_cap, uint32_t nseg, int dbg) {
+                                                              uint64_t list_cap, uint32_t pieces, uint32_t nseg,
+                                                              int dbg) {
     extern __shared__ uint64_t s_seg[];  // 2^S slots
     const uint32_t nslots = 1u << p.S;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint64_t n = list_start ? (uint64_t)list_cnt[seg] : min((uint64_t)list_cnt[seg], list_cap);
+        // a segment's keys: one packed run (list_start) or up to 8 sub-lists of list_cap.
+        // e[c] = number of keys in sub-lists 0..c (wave-uniform, stays in scalar registers)
+        uint64_t e[8];
+        uint64_t n = 0;
+        const uint64_t *in0;
+        if (list_start) {
+            n = (uint64_t)list_cnt[seg];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) e[c] = n;
+            in0 = lists + (uint64_t)list_start[seg];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if ((uint32_t)c < pieces) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
+                e[c] = n;
+            }
+            in0 = lists + (uint64_t)seg * pieces * list_cap;
+        }
         if (n == 0) continue;
         uint64_t *slots = p.table + ((uint64_t)seg << p.S);
         const bool dirty = p.seg_dirty[seg] != 0;
-        __syncthreads();  // previous segment fully written out
+        lds_barrier();  // previous segment fully written out
         if (dirty) {
             for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
                 *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
@@ -285,18 +341,25 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
             for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
                 *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
         }
-        __syncthreads();
-        const uint64_t *in = lists + (list_start ? (uint64_t)list_start[seg] : (uint64_t)seg * list_cap);
+        lds_barrier();
+        auto fetch = [&](uint64_t idx) -> uint64_t {  // idx-th key of the segment, 0 past the end
+            if (idx >= n) return 0;
+            uint64_t c = 0, before = 0;
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+                if (idx >= e[t]) { c = t + 1; before = e[t]; }
+            return in0[c * list_cap + (idx - before)];
+        };
         const uint64_t one = 1ULL << p.cshift;
         // Every lane streams its own keys (tid, tid+nt, ...): one probe per loop round,
         // and a lane that has placed its key moves straight on to its next one, so the
         // wave stays full until the lists run dry instead of idling on its longest probe
         // chain.  Three keys per lane are always in flight from HBM.
         uint64_t r = tid;
-        uint64_t cur = (r < n) ? in[r] : 0;
-        uint64_t f1 = (r + nt < n) ? in[r + nt] : 0;
-        uint64_t f2 = (r + 2ULL * nt < n) ? in[r + 2ULL * nt] : 0;
-        uint64_t f3 = (r + 3ULL * nt < n) ? in[r + 3ULL * nt] : 0;
+        uint64_t cur = fetch(r);
+        uint64_t f1 = fetch(r + nt);
+        uint64_t f2 = fetch(r + 2ULL * nt);
+        uint64_t f3 = fetch(r + 3ULL * nt);
         bool live = (r < n) && !(dbg & 2);
         uint32_t i = 1;
         while (live) {
@@ -321,13 +384,13 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
                 r += nt;
                 live = r < n;
                 cur = f1; f1 = f2; f2 = f3;
-                f3 = (r + 3ULL * nt < n) ? in[r + 3ULL * nt] : 0;
+                f3 = fetch(r + 3ULL * nt);
                 i = 1;
             } else {
                 ++i;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (!(dbg & 4))
             for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
                 *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);

@@ -375,7 +375,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     // once (2 x table bytes at worst), the atomic path pays ~60 ps per k-mer.
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
-    const bool can_part = (p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 17);
+    const bool can_part = (p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 16);  // two levels of <= 256 lists
     const bool use_part = can_part && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes));
     if (!use_part) {
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
@@ -394,7 +394,12 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const uint32_t nb1 = 1u << b1, nb2 = 1u << b2;
     auto even = [](uint64_t v) { return (v + 1) & ~1ULL; };
     const uint64_t log_cap = even(maxrec / g3 + maxrec / g3 / 3 + 2048);
-    const uint64_t cap_seg = even(maxrec / nseg + maxrec / nseg / 4 + 512);
+    // level 2 runs cpr2 workgroups per level-1 bucket; each owns one sub-list per segment
+    uint32_t cpr2 = b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / nb1)) : 1;
+    if (b2) if (const char *e = getenv("TSX_HIP_CPR2")) cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    const uint64_t per_sub = maxrec / nseg / cpr2;
+    const uint64_t cap_sub = even(per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64);
+    const uint64_t cap_seg = cap_sub * cpr2;
     // buffer 0: key log, later the segment lists of a two-level split; buffer 1: level-1 lists
     const size_t need0 = std::max<uint64_t>((uint64_t)g3 * log_cap, b2 ? (uint64_t)nseg * cap_seg : 0) * 8;
     const size_t need1 = (uint64_t)g3 * log_cap * 8;  // packed level-1 output: never more keys than the log
@@ -409,7 +414,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         }
     // counters: [log fill per workgroup | level-1 bucket start | level-1 bucket size | segment list size]
     // then the level-1 histogram matrix (u32) and its exclusive scan (u64), both nb1 x g3
-    const size_t cnt_need = (size_t)g3 + 2 * (size_t)nb1 + nseg;
+    const size_t cnt_need = (size_t)g3 + 2 * (size_t)nb1 + (size_t)nseg * cpr2;
     const size_t mat = (size_t)nb1 * g3;
     const size_t cnt_bytes = cnt_need * 8 + mat * 8 + mat * 4 + 64;
     if (cnt_bytes > m->cnt_entries) {
@@ -420,7 +425,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         m->cnt_entries = cnt_bytes + 4096;
     }
     unsigned long long *c_log = m->d_cnt, *c_bstart = c_log + g3, *c_bcnt = c_bstart + nb1, *c_seg = c_bcnt + nb1;
-    unsigned long long *d_offs = c_seg + nseg;
+    unsigned long long *d_offs = c_seg + (size_t)nseg * cpr2;
     uint32_t *d_hist = reinterpret_cast<uint32_t *>(d_offs + mat);
     HIP_TRY(hipMemsetAsync(m->d_cnt, 0, cnt_need * 8, st));
 
@@ -432,43 +437,46 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
 
     static bool attr_done = false;
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)partition_private_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
         attr_done = true;
     }
-    auto part_lds = [](uint32_t nb, uint32_t cap) { return (size_t)nb * ((size_t)cap * 8 + 20); };
-    // staging depth: 7 keys may stay behind a flush, plus a batch's arrivals (Poisson, mean = batch / nb)
-    auto stage_cap = [](uint32_t threads, uint32_t nb) {
-        const uint32_t mean = std::max<uint32_t>(1, threads * PART_RPT / nb);
-        return std::min<uint32_t>(64, 8 + mean + 6 * (uint32_t)std::ceil(std::sqrt((double)mean)) + 4);
+    // ring depth: 7 keys may stay behind a flush, plus one batch's arrivals (mean = batch / nb)
+    auto ring_bits = [](uint32_t nb) {
+        const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_RPT / nb);
+        uint32_t bits = 4;
+        while ((1u << bits) < 8 + 2 * mean && bits < 6) ++bits;
+        return bits;
     };
+    auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 32); };
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)d_hist, d_offs, nb1, (uint32_t)g3,
                        c_bstart, c_bcnt);
     {   // level 1: every workgroup's key log -> packed array ordered by the top b1 bits of the home slot
-        const uint32_t cap = stage_cap(PART_NT, nb1);
-        hipLaunchKernelGGL(partition_private_kernel, dim3(g3), dim3(PART_NT), part_lds(nb1, cap), st, m->p,
+        const uint32_t bits = ring_bits(nb1);
+        hipLaunchKernelGGL(partition_ring_kernel, dim3(g3), dim3(PART_NT), part_lds(nb1, bits), st, m->p,
                            (const uint64_t *)m->d_buf[0], (const unsigned long long *)nullptr,
-                           (const unsigned long long *)c_log, log_cap, (uint32_t)g3, m->d_buf[1],
+                           (const unsigned long long *)c_log, log_cap, (uint32_t)g3, 1u, m->d_buf[1],
                            (const unsigned long long *)d_offs, (unsigned long long *)nullptr, (uint64_t)0, nb1,
-                           (uint32_t)(p.l - b1), cap);
+                           (uint32_t)(p.l - b1), bits);
         HIP_TRY(hipGetLastError());
     }
     const uint64_t *lists = m->d_buf[1];
     const unsigned long long *lists_start = c_bstart, *lists_cnt = c_bcnt;
     uint64_t lists_cap = 0;
-    if (b2) {  // level 2: one workgroup per level-1 bucket -> nb2 segment lists each
-        const uint32_t thr = 1024, cap = stage_cap(thr, nb2);
-        hipLaunchKernelGGL(partition_private_kernel, dim3(nb1), dim3(thr), part_lds(nb2, cap), st, m->p,
+    uint32_t pieces = 1;
+    if (b2) {  // level 2: cpr workgroups per level-1 bucket, each with its own sub-list per segment
+        const uint32_t bits = ring_bits(nb2);
+        hipLaunchKernelGGL(partition_ring_kernel, dim3(nb1 * cpr2), dim3(PART_NT), part_lds(nb2, bits), st, m->p,
                            (const uint64_t *)m->d_buf[1], (const unsigned long long *)c_bstart,
-                           (const unsigned long long *)c_bcnt, (uint64_t)0, nb1, m->d_buf[0],
-                           (const unsigned long long *)nullptr, c_seg, cap_seg, nb2, (uint32_t)p.S, cap);
+                           (const unsigned long long *)c_bcnt, (uint64_t)0, nb1, cpr2, m->d_buf[0],
+                           (const unsigned long long *)nullptr, c_seg, cap_sub, nb2, (uint32_t)p.S, bits);
         HIP_TRY(hipGetLastError());
-        lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = c_seg; lists_cap = cap_seg;
+        lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = c_seg; lists_cap = cap_sub; pieces = cpr2;
     }
     if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
         const int gb = (int)std::min<uint32_t>(nseg, (uint32_t)m->cus * 4);
         hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_start,
-                           lists_cnt, lists_cap, nseg, m->dbg);
+                           lists_cnt, lists_cap, pieces, nseg, m->dbg);
         HIP_TRY(hipGetLastError());
     }
     if (ev) HIP_TRY(hipEventRecord(ev[3], st));
