@@ -21,46 +21,57 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(k, seed, max_seconds=90):
+def cpu_baseline(k, seed, max_seconds=60):
     """Time the real reference (oracle/_ref/tsxCount_ref, --mode=CAS) on a bounded
-    sample of the same synthetic reads, on this box's host cores."""
+    sample of the same synthetic reads, on this box's host cores.
+
+    The reference's CAS mode is not robust under threads (unsynchronised
+    std::set inserts and retry loops: it live-locks at 16 threads on this input and
+    sometimes crashes at 8), so thread counts are tried from 8 downwards and the
+    first run that exits 0 is reported, with the failed attempts listed."""
     from tsxcount_amd import synth
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "tsxCount_ref")
+    attempts = []
+    if os.path.exists(ref_bin):
+        for threads, n_reads in ((8, 3000), (8, 3000), (4, 1500), (2, 800), (1, 400)):
+            threads = max(1, min(threads, os.cpu_count() or 1))
+            text = synth.fastq(seed, 0, n_reads)
+            nrand, na = synth.read_lengths(seed, 0, n_reads)
+            kmers = int(((nrand + na) - k + 1).clip(min=0).sum())
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "sample.fastq")
+                with open(path, "wb") as f:
+                    f.write(text)
+                # 2k+s must be a multiple of 8 for the reference's byte-wise CAS
+                # stores to stay aligned (TSXHashMapCAS.h:141-232): k=31 -> s=2.
+                cmd = [ref_bin, "--input=" + path, "--k=%d" % k, "--l=23", "--s=2", "--mode=CAS",
+                       "--threads=%d" % threads]
+                t0 = time.time()
+                try:
+                    rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                        timeout=max_seconds).returncode
+                except subprocess.TimeoutExpired:
+                    rc = "timeout"
+                dt = time.time() - t0
+            if rc == 0:
+                return {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "reference",
+                        "sample": "%d synthetic reads (%d k-mers), k=%d, tsxCount --mode=CAS --l=23 --s=2 "
+                                  "--threads=%d, wall time of the whole run" % (n_reads, kmers, k, threads),
+                        "failed_attempts": attempts}
+            attempts.append({"threads": threads, "reads": n_reads, "rc": rc, "seconds": round(dt, 1)})
+    # fall back to the C restatement (single core)
+    from oracle.oracle import Oracle
     n_reads = 3000
     text = synth.fastq(seed, 0, n_reads)
     nrand, na = synth.read_lengths(seed, 0, n_reads)
     kmers = int(((nrand + na) - k + 1).clip(min=0).sum())
-    # The reference's CAS mode live-locks on this input at 16 threads on the GPU box
-    # (unsynchronised retries, "INC KEY VAL CAS 0"); 8 threads completes.
-    cores = max(1, min(8, os.cpu_count() or 1))
-    sample = "%d synthetic reads (%d k-mers), k=%d" % (n_reads, kmers, k)
-    if os.path.exists(ref_bin):
-        with tempfile.TemporaryDirectory() as td:
-            path = os.path.join(td, "sample.fastq")
-            with open(path, "wb") as f:
-                f.write(text)
-            # 2k+s must be a multiple of 8 for the reference's byte-wise CAS
-            # stores to stay aligned (TSXHashMapCAS.h:141-232): k=31 -> s=2.
-            cmd = [ref_bin, "--input=" + path, "--k=%d" % k, "--l=23", "--s=2", "--mode=CAS",
-                   "--threads=%d" % cores]
-            t0 = time.time()
-            try:
-                rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                    timeout=max_seconds).returncode
-            except subprocess.TimeoutExpired:
-                rc = -1
-            dt = time.time() - t0
-        if rc == 0:
-            return {"value": kmers / dt, "unit": "k-mers/s", "cores": cores, "kind": "reference",
-                    "sample": sample + ", tsxCount --mode=CAS --l=23 --s=2, wall time of the whole run"}
-    # fall back to the C restatement (single core)
-    from oracle.oracle import Oracle
     o = Oracle(k, 23, 2, seed=1)
     t0 = time.time()
     o.count_fastq(text)
     dt = time.time() - t0
     return {"value": kmers / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": sample + ", oracle/tsx_oracle.c serial"}
+            "sample": "%d synthetic reads (%d k-mers), k=%d, oracle/tsx_oracle.c serial" % (n_reads, kmers, k),
+            "failed_attempts": attempts}
 
 
 def main():
@@ -146,16 +157,26 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = kmers_total * args.steps / elapsed
-        # roofline of the dominant kernel (count_fastq_kernel): algorithmic bytes per launch
-        # = FASTQ bytes read once + 16 B (8 B slot read + 8 B slot write) per k-mer occurrence
-        kern_ms = count_ms / max(launches, 1)
-        alg_bytes = nbytes + 16.0 * kmers_rank
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # Roofline.  Per k-mer the path must at least read its share of the text and read +
+        # write one 8-byte slot: algorithmic bytes = text bytes + 16 B x k-mer occurrences
+        # (DESIGN.md section 3).  Reported for the dominant kernel (the scan kernel, which in
+        # the partitioned path reads the text and writes one 8-byte key per logged k-mer) and
+        # for the whole device path of a step.
+        pieces = max(launches, 1)
+        kern_ms = count_ms / pieces
+        partitioned = build_ms / pieces > 0.5
+        keys_logged = st["distinct"] if partitioned else 0
+        kern_bytes = nbytes + (8.0 * keys_logged if partitioned else 16.0 * kmers_rank)
+        achieved = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        path_bytes = nbytes + 16.0 * kmers_rank
+        path_ms = (scan_ms + count_ms + build_ms) / pieces
         traffic = None
+        prof = {}
         pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                prof = json.load(open(pmc))
+                traffic = prof.get("partitioned" if partitioned else "atomic", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -164,16 +185,19 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "synthetic FASTQ (generateFakeSequences.py shape), %d reads/GPU = %d k-mers/GPU, "
-                                   "k=%d, table 2^%d slots/GPU%s" % (args.reads, kmers_rank, args.k, args.l,
-                                                                      ", per-GPU tables merged over RCCL all-to-all"
-                                                                      if world > 1 else ""),
+                                   "k=%d, table 2^%d slots/GPU, %s insert path%s"
+                                   % (args.reads, kmers_rank, args.k, args.l,
+                                      "partitioned" if partitioned else "atomic",
+                                      ", per-GPU tables merged over RCCL all-to-all" if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
                        "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL"},
             "roofline": {"bound": "hbm", "kernel": "count_fastq_kernel<1>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": kern_ms, "line_pass_ms": scan_ms / max(launches, 1),
-                         "partition_build_ms": build_ms / max(launches, 1),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
+                         "line_pass_ms": scan_ms / pieces, "partition_build_ms": build_ms / pieces,
+                         "whole_path": {"algorithmic_bytes": path_bytes, "device_ms": path_ms,
+                                        "achieved": path_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
+                                        "frac": (path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_ms > 0 else 0.0}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.k, args.seed)

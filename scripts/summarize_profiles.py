@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_r1 (scripts/profile_round1.sh) into the committed summaries
+under profiles/: kernel stats per insert path, PMC counters per kernel, and
+round1_pmc.json (HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes:
+FETCH_SIZE tallies 128-B read requests at 64 B on gfx950 -> x2; both are in KiB)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r1")
+DST = os.path.join(ROOT, "profiles")
+TEXT_BYTES = 2081065118
+
+for path in ("partitioned", "atomic"):
+    f = glob.glob(os.path.join(SRC, "trace_" + path, "*", "*_kernel_stats.csv"))
+    if f:
+        shutil.copy(f[0], os.path.join(DST, "round1_kernel_stats_%s.csv" % path))
+
+agg = collections.defaultdict(dict)
+for f in sorted(glob.glob(os.path.join(SRC, "pmc_partitioned_*", "*", "*_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][r["Counter_Name"]] = agg[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+with open(os.path.join(DST, "round1_pmc_counters_partitioned.csv"), "w") as out:
+    out.write("kernel,counter,sum_over_dispatches_of_one_bench_run(steps=1,warmup=0)\n")
+    for k in sorted(agg):
+        for c in sorted(agg[k]):
+            out.write("%s,%s,%.3f\n" % (k, c, agg[k][c]))
+
+summary_path = os.path.join(DST, "round1_pmc.json")
+summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {}
+if "kernel" in summary:  # first layout of this file: the atomic path only
+    summary = {"atomic": summary}
+part = {"command": "rocprofv3 --pmc <set> --output-format csv -- python3 bench.py --steps 1 --warmup 0 "
+                   "--no-cpu-baseline (one pass per counter set, default = partitioned path, l=30)",
+        "kernels": {}}
+tot_r = tot_w = 0.0
+for k, v in agg.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v and not k.startswith("__amd") and "synth" not in k and "occupied" not in k:
+        rd, wr = v["FETCH_SIZE"] * 1024 * 2, v["WRITE_SIZE"] * 1024
+        part["kernels"][k] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr,
+                              "TCC_EA0_ATOMIC_sum": v.get("TCC_EA0_ATOMIC_sum")}
+        tot_r += rd
+        tot_w += wr
+scan = part["kernels"].get("tsx::count_fastq_kernel<1>", {})
+part["kernel"] = "tsx::count_fastq_kernel<1>"
+part["hbm_bytes_per_launch"] = scan.get("hbm_read_bytes", 0) + scan.get("hbm_write_bytes", 0)
+part["hbm_bytes_whole_path_per_step"] = tot_r + tot_w
+lc = agg.get("tsx::line_count_kernel", {})
+if "FETCH_SIZE" in lc:
+    part["calibration"] = ("line_count_kernel streams the %d-byte text once: FETCH_SIZE*1024*2 = %.0f bytes (%.3fx)"
+                           % (TEXT_BYTES, lc["FETCH_SIZE"] * 2048, lc["FETCH_SIZE"] * 2048 / TEXT_BYTES))
+summary["partitioned"] = part
+json.dump(summary, open(summary_path, "w"), indent=1)
+print(json.dumps(part, indent=1))
