@@ -45,6 +45,8 @@ typedef struct tsx_hip_layout {
     int32_t reprobe_bits;   /* width of the reprobe field stored next to them */
     int32_t count_bits;     /* in-slot counter width ("storage bits", TSXHashMap.h:83) */
     int32_t overflow_l;     /* log2 slots of the secondary overflow array */
+    int32_t shard_bits;     /* the whole table has 2^(l+shard_bits) slots spread over 2^shard_bits GPUs */
+    int32_t shard_index;    /* this GPU holds home slots [shard_index << l, (shard_index+1) << l) */
     uint32_t max_reprobes;  /* probes tried before TSX_HIP_EFULL */
     uint64_t slots;         /* 2^l (getMaxElements, TSXHashMap.h:162) */
     uint64_t table_bytes;   /* device bytes of the primary table */
@@ -86,6 +88,15 @@ int tsx_hip_decode(const uint64_t *limbs, int k, char *out);
  */
 int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
                    uint64_t hash_seed, int device);
+/*
+ * One shard of a table that spans 2^shard_bits GPUs (one process per GPU): the whole
+ * table has 2^(l + shard_bits) slots, this map holds the slot range of shard_index.
+ * The owner of a k-mer is the top shard_bits bits of its home slot.  Inserts and
+ * lookups of k-mers that another shard owns are ignored / answer 0, so the same
+ * batch can be offered to every shard.  shard_bits = 0 is tsx_hip_create.
+ */
+int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
+                         uint64_t hash_seed, int device, int shard_bits, int shard_index);
 void tsx_hip_destroy(tsx_hip_map *m);
 int tsx_hip_get_layout(const tsx_hip_map *m, tsx_hip_layout *out);
 /* Zero the table, the secondary array and the counters. */
@@ -172,6 +183,29 @@ int tsx_hip_owner_host(const tsx_hip_map *m, const uint64_t *kmer, int nranks);
 int tsx_hip_hash_apply(const tsx_hip_map *m, const uint64_t *kmer, uint64_t *key_out);
 int tsx_hip_hash_invert(const tsx_hip_map *m, const uint64_t *key, uint64_t *kmer_out);
 int tsx_hip_hash_rows(const tsx_hip_map *m, uint64_t *rows_out /* 2k x key_limbs */);
+
+/*
+ * Multi-GPU counting with a sharded table (k <= 32).  Reads shard across the GPUs;
+ * what travels between them is hashed keys BEFORE they are built into a table, not
+ * table slots afterwards:
+ *   shard_scan_device   scans this GPU's reads and writes the hashed keys of all
+ *                       k-mers, grouped by owner GPU, into dev_send (capacity from
+ *                       tsx_hip_shard_send_capacity); dev_send_counts[o] = keys for
+ *                       owner o.  Keys that carry a count (hot k-mers merged on chip)
+ *                       go to the (dev_hot_keys, dev_hot_counts) list, *dev_hot_n of them.
+ *   -- all-to-all of the owner groups (RCCL), all-gather of the hot lists --
+ *   shard_build_device  builds the received keys into this GPU's slot range
+ *                       (radix partition + LDS segment build);
+ *   add_hashed_device   adds (hashed key, count) pairs, skipping other owners' keys.
+ * tsxcount_amd/distributed.py: count_fastq_sharded().
+ */
+int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, size_t *keys_out);
+int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, size_t n, void *dev_send,
+                              size_t send_cap_keys, void *dev_send_counts, void *dev_hot_keys,
+                              void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *stream);
+int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *stream);
+int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
+                              void *stream);
 
 /*
  * Synthetic reads shaped like generateFakeSequences.py (500-1000 random bases

@@ -1,0 +1,53 @@
+"""Worker of test_sharded_counting_on_one_gpu (not a pytest file): 2 ranks share cuda:0."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = port
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import tsxcount_amd as T  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+from tsxcount_amd import distributed as TD  # noqa: E402
+from tsxcount_amd import synth  # noqa: E402
+
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+bits = world.bit_length() - 1
+for k, l, n_reads in ((31, 17, 240), (21, 15, 30), (32, 19, 700)):
+    first, cnt = TD.shard_reads(n_reads, rank, world)
+    text = synth.fastq(66, first, cnt)
+    buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")
+    m = T.TSXHashMapHIP(l, 0, k, device=0, shard_bits=bits, shard_index=rank)
+    sc = TD.ShardedCounter(m, len(text))
+    torch.cuda.synchronize()
+    for rep in (1, 2):  # second pass merges into segments that already hold data
+        sc.step(buf.data_ptr(), len(text))
+        whole = Oracle(k, 21, 4, seed=1)
+        whole.count_fastq(synth.fastq(66, 0, n_reads))
+        kmers, counts = whole.dump()
+        got = m.getKmerCounts(kmers)
+        tot = torch.from_numpy(got.astype(np.int64))
+        dist.all_reduce(tot)
+        assert np.array_equal(tot.numpy().astype(np.uint64), rep * counts), "sum over shards != oracle"
+        owned = got > 0
+        others = torch.from_numpy(owned.astype(np.int64))
+        dist.all_reduce(others)
+        assert (others.numpy() == 1).all(), "every k-mer must live on exactly one shard"
+        st = m.stats()
+        assert st["insert_failures"] == 0 and st["distinct"] == int(owned.sum())
+        # the dump of a shard reconstructs full k-mers (owner bits included)
+        dk, dc = m.getAllKmers()
+        assert np.array_equal(np.sort(dk[:, 0]), np.sort(kmers[owned][:, 0]))
+    frac = owned.mean()
+    assert 0.2 < frac < 0.8, "slot-range ownership should split the keys roughly evenly"
+    m.close()
+dist.barrier()
+dist.destroy_process_group()
+print("SHARD OK rank", rank)

@@ -30,7 +30,8 @@ class Layout(ctypes.Structure):
     _fields_ = [("k", ctypes.c_int32), ("l", ctypes.c_int32), ("key_limbs", ctypes.c_int32),
                 ("entry_limbs", ctypes.c_int32), ("func_bits", ctypes.c_int32),
                 ("reprobe_bits", ctypes.c_int32), ("count_bits", ctypes.c_int32),
-                ("overflow_l", ctypes.c_int32), ("max_reprobes", ctypes.c_uint32),
+                ("overflow_l", ctypes.c_int32), ("shard_bits", ctypes.c_int32), ("shard_index", ctypes.c_int32),
+                ("max_reprobes", ctypes.c_uint32),
                 ("slots", ctypes.c_uint64), ("table_bytes", ctypes.c_uint64)]
 
 
@@ -71,6 +72,11 @@ def lib():
     L.tsx_hip_encode.argtypes = [ctypes.c_char_p, ci, u64p]
     L.tsx_hip_decode.argtypes = [u64p, ci, ctypes.c_char_p]
     L.tsx_hip_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, u64, ci]
+    L.tsx_hip_create_shard.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, u64, ci, ci, ci]
+    L.tsx_hip_shard_send_capacity.argtypes = [vp, sz, ctypes.POINTER(sz)]
+    L.tsx_hip_shard_scan_device.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp, vp]
+    L.tsx_hip_shard_build_device.argtypes = [vp, vp, sz, vp]
+    L.tsx_hip_add_hashed_device.argtypes = [vp, vp, vp, sz, vp]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None
     L.tsx_hip_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]
@@ -149,11 +155,12 @@ class TSXHashMapHIP:
     (TSXHashMap.h:79); method names follow the reference class.
     """
 
-    def __init__(self, iL, iStorageBits, iK, iThreads=0, hash_seed=1, overflow_l=0, device=0):
+    def __init__(self, iL, iStorageBits, iK, iThreads=0, hash_seed=1, overflow_l=0, device=0, shard_bits=0,
+                 shard_index=0):
         self._h = ctypes.c_void_p()
         self._lib = lib()
-        _check(self._lib.tsx_hip_create(ctypes.byref(self._h), iK, iL, iStorageBits, overflow_l,
-                                        hash_seed, device))
+        _check(self._lib.tsx_hip_create_shard(ctypes.byref(self._h), iK, iL, iStorageBits, overflow_l,
+                                              hash_seed, device, shard_bits, shard_index))
         self.layout = Layout()
         _check(self._lib.tsx_hip_get_layout(self._h, ctypes.byref(self.layout)))
         self.k, self.l, self.wk, self.device = iK, iL, self.layout.key_limbs, device

@@ -49,6 +49,9 @@ struct TableParams {
     int k, l, n, wk, W;
     int R, F, C, K0, cshift;    // cshift = 64 - C
     int S;                      // log2 slots per segment
+    int lg;                     // log2 slots of the WHOLE table: l on one GPU, l + shard_bits when the
+                                // table is sharded by slot range over 2^shard_bits GPUs
+    uint32_t shard;             // this GPU's slot range: home slots [shard << l, (shard + 1) << l)
     int g, groups;              // LUT granularity (4 or 8 bits) and group count
     uint32_t max_reprobes;
 };
@@ -130,8 +133,8 @@ __device__ __forceinline__ void split_key(const TableParams &p, const uint64_t (
     uint64_t f[WK + 1];
 #pragma unroll
     for (int t = 0; t < WK; ++t) {
-        uint64_t v = h[t] >> p.l;
-        if (t + 1 < WK) v |= h[t + 1] << (64 - p.l);
+        uint64_t v = h[t] >> p.lg;
+        if (t + 1 < WK) v |= h[t + 1] << (64 - p.lg);
         f[t] = v;
     }
     f[WK] = 0;
@@ -146,6 +149,12 @@ __device__ __forceinline__ void split_key(const TableParams &p, const uint64_t (
     // hi = fr >> K0 (1 <= K0 <= 63)
 #pragma unroll
     for (int t = 0; t < 4; ++t) hi[t] = (fr[t] >> p.K0) | (fr[t + 1] << (64 - p.K0));
+}
+
+// Which shard owns a hashed key: the bits of its home slot above the local l bits.
+template <int WK>
+__device__ __forceinline__ uint32_t owner_shard(const TableParams &p, const uint64_t (&h)[WK]) {
+    return (uint32_t)((h[0] >> p.l) & ((1ULL << (p.lg - p.l)) - 1ULL));
 }
 
 // addKmer (TSXHashMap.h:182-350, CAS form TSXHashMapCAS.h:268-508) for one
@@ -214,6 +223,7 @@ __device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK],
 // launch after every insert kernel has finished.
 template <int WK>
 __device__ inline uint64_t lookup_key(const TableParams &p, const uint64_t (&h)[WK]) {
+    if (p.lg != p.l && owner_shard<WK>(p, h) != p.shard) return 0;  // lives on another GPU
     uint64_t pos0, e0, hi[4];
     split_key<WK>(p, h, pos0, e0, hi);
     const int W = p.W;

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                                                          uint64_t own_end, int head_open,
                                                          const uint32_t *tile_line, uint64_t ntiles, int dbg,
                                                          uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt,
-                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift) {
+                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift,
+                                                         uint64_t *hot_keys, uint64_t *hot_cnts, uint64_t hot_cap,
+                                                         unsigned long long *hot_n) {
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
     __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
     __shared__ uint64_t s_le[TILE / 64];
@@ -184,6 +186,18 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     // region of the key log instead of the table; no global atomic is involved
     uint64_t *my_log = log ? log + (uint64_t)blockIdx.x * log_cap : nullptr;
     uint32_t log_fill = 0;  // identical in every thread
+    // Sharded table: keys that bypass the log (hot keys, a full log region) may belong to
+    // another GPU, so they go to a small (key, count) list that is exchanged instead of
+    // into the local table.
+    auto side_insert = [&](const uint64_t (&hkey)[WK], uint64_t d) {
+        if (hot_keys) {
+            const unsigned long long at = atomicAdd(hot_n, 1ULL);
+            if (at < hot_cap) { hot_keys[at] = hkey[0]; hot_cnts[at] = d; }
+            else atomicAdd(&p.stats[ST_FAIL], (unsigned long long)d);
+        } else {
+            insert_key<WK>(p, hkey, d);
+        }
+    };
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                                 for (int q = 0; q < HOT_N; ++q)
                                     if (!hcnt[q]) { at = q; hkey[q] = hk[j][0]; break; }
                             if (at >= 0 && (uint64_t)hcnt[at] + d < 0xFFFFFFF0ULL) hcnt[at] += (uint32_t)d;
-                            else insert_key<WK>(p, hk[j], d);
+                            else side_insert(hk[j], d);
                         }
                     }
                     wave_emit += (uint32_t)__builtin_popcountll(__ballot(d == 1));
@@ -334,7 +348,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                             my_log[at] = hk[j][0];
                             if (hist) atomicAdd(&s_hist[(uint32_t)(hk[j][0] >> hist_shift) & (hist_nb - 1)], 1u);
                         } else if (!(dbg & 1)) {
-                            insert_key<WK>(p, hk[j], 1);  // region full: atomic path
+                            side_insert(hk[j], 1);  // region full: atomic path
                         }
                     }
                     off += (uint32_t)__builtin_popcountll(mk);
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
         lds_barrier();
         if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) {
             const uint64_t h1[WK] = {s_hot_key[tid]};
-            insert_key<WK>(p, h1, s_hot_cnt[tid]);
+            side_insert(h1, s_hot_cnt[tid]);
         }
     }
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
@@ -373,6 +387,7 @@ __global__ __launch_bounds__(NT) void add_kmers_kernel(TableParams p, const uint
         const uint64_t d = counts ? counts[i] : 1ULL;
         if (d == 0) continue;
         hash_apply<WK>(p, p.lut, x, h);
+        if (p.lg != p.l && owner_shard<WK>(p, h) != p.shard) continue;  // another GPU's slot range
         insert_key<WK>(p, h, d);
         added += d;
     }
@@ -435,11 +450,11 @@ __device__ __forceinline__ void slot_to_kmer(const TableParams &p, uint64_t pos,
     func[5] = 0;
 #pragma unroll
     for (int t = 0; t < WK; ++t) {
-        uint64_t hv = func[t] << p.l;
-        if (t > 0) hv |= func[t - 1] >> (64 - p.l);
+        uint64_t hv = func[t] << p.lg;
+        if (t > 0) hv |= func[t - 1] >> (64 - p.lg);
         h[t] = hv;
     }
-    h[0] |= pos0;
+    h[0] |= pos0 | ((uint64_t)p.shard << p.l);
     h[WK - 1] &= p.top_mask;
     hash_apply<WK>(p, p.ilut, h, x);
     count = (v >> p.cshift) + (sec_get(p, pos) << p.C);

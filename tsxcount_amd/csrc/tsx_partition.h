@@ -298,6 +298,72 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *hist, uns
         bucket_cnt[b] = ((b + 1 < nb) ? bucket_start[b + 1] : grand) - bucket_start[b];
 }
 
+// Level 0 of a sharded run: split this workgroup's key log by owner GPU (fan-out
+// 2..8) into the packed send buffer, at the exact offsets offsets_kernel derived
+// from the scan kernel's per-owner histograms.  With so few lists no staging is
+// needed: per destination one ballot gives every lane its place in a contiguous
+// run, so consecutive lanes write consecutive keys.
+__global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *src, const unsigned long long *src_cnt,
+                                                              uint64_t src_cap, uint32_t nregions, uint64_t *dst,
+                                                              const unsigned long long *offs, uint32_t nown,
+                                                              uint32_t shift) {
+    __shared__ unsigned long long s_cur[8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+        lds_barrier();
+        if (tid < nown) s_cur[tid] = offs[(size_t)tid * nregions + r];
+        lds_barrier();
+        const uint64_t n = min((uint64_t)src_cnt[r], src_cap);
+        const uint64_t *in = src + (uint64_t)r * src_cap;
+        for (uint64_t base = 0; base < n; base += PART_NT) {
+            const uint64_t i = base + tid;
+            const bool have = i < n;
+            const uint64_t key = have ? in[i] : 0;
+            const uint32_t o = have ? ((uint32_t)(key >> shift) & (nown - 1)) : 0xFFFFFFFFu;
+            for (uint32_t d = 0; d < nown; ++d) {
+                const unsigned long long mk = __ballot(o == d);
+                if (mk == 0ULL) continue;
+                unsigned long long at = 0;
+                if (lane == (uint32_t)__builtin_ctzll(mk))
+                    at = atomicAdd(&s_cur[d], (unsigned long long)__builtin_popcountll(mk));
+                at = __shfl(at, __builtin_ctzll(mk), 64);
+                if (o == d) dst[at + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = key;
+            }
+        }
+    }
+}
+
+// Level-1 histogram of an arbitrary key array cut into G equal regions (the keys a
+// shard received): hist[b * G + g], the layout offsets_kernel scans.
+__global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uint64_t n, uint64_t region_len,
+                                                       uint32_t G, uint32_t nb, uint32_t shift, uint32_t *hist,
+                                                       unsigned long long *region_start, unsigned long long *region_cnt) {
+    __shared__ uint32_t s_h[256];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
+        lds_barrier();
+        for (uint32_t b = tid; b < nb; b += PART_NT) s_h[b] = 0;
+        lds_barrier();
+        const uint64_t lo = min(n, (uint64_t)g * region_len), hi = min(n, lo + region_len);
+        for (uint64_t i = lo + tid; i < hi; i += PART_NT) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & (nb - 1)], 1u);
+        lds_barrier();
+        for (uint32_t b = tid; b < nb; b += PART_NT) hist[(size_t)b * G + g] = s_h[b];
+        if (tid == 0) { region_start[g] = lo; region_cnt[g] = hi - lo; }
+    }
+}
+
+// addKmer for HASHED keys with counts (the exchanged hot-key lists of a sharded run);
+// keys of other shards are skipped.
+__global__ __launch_bounds__(PART_NT) void add_hashed_kernel(TableParams p, const uint64_t *keys, const uint64_t *counts,
+                                                             uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * PART_NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PART_NT) {
+        const uint64_t h[1] = {keys[i]};
+        const uint64_t d = counts ? counts[i] : 1ULL;
+        if (d == 0 || owner_shard<1>(p, h) != p.shard) continue;
+        insert_key<1>(p, h, d);
+    }
+}
+
 // One workgroup builds one segment: slots [seg << S, (seg+1) << S) live in LDS
 // while the segment's key list is inserted with LDS atomics (same slot format,
 // same probe sequence as insert_key), then go back to HBM in one sweep.
@@ -364,7 +430,7 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
         uint32_t i = 1;
         while (live) {
             const uint32_t q0 = (uint32_t)(cur & p.seg_mask);
-            const uint64_t key0 = (((cur >> p.l) << p.R) & p.k0mask) | i;  // split_key for WK = 1
+            const uint64_t key0 = (((cur >> p.lg) << p.R) & p.k0mask) | i;  // split_key for WK = 1
             const uint32_t q = (q0 + ((i * (i + 1)) >> 1)) & (uint32_t)p.seg_mask;
             const unsigned long long old =
                 atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));

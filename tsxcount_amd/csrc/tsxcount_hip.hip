@@ -50,6 +50,7 @@ struct tsx_hip_map {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
     size_t piece = STAGE_PIECE_DEFAULT;  // TSX_HIP_PIECE_BYTES overrides (tests exercise piece seams)
+    bool piece_fixed = false;
     int cus = 256;
     // partitioned insert path (tsx_partition.h): grow-only scratch
     int path = 0;                    // 0 auto, 1 atomic, 2 partitioned (tsx_hip_set_path / TSX_HIP_PATH)
@@ -175,13 +176,15 @@ static void make_lut(const tsx_hip_map *m, const std::vector<uint64_t> &rows, st
 }
 
 // ---- layout -------------------------------------------------------------------
-static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l) {
+static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l, int shard_bits, int shard_index) {
     if (k < 1 || k > 127 || l < 4 || l > 36 || s < 0 || s > 32) return TSX_HIP_EINVAL;
-    if (2 * k <= l) return TSX_HIP_EINVAL;  // TSXHashMap.h:91-94
+    if (shard_bits < 0 || shard_bits > 3 || shard_index < 0 || shard_index >= (1 << shard_bits)) return TSX_HIP_EINVAL;
+    if (2 * k <= l + shard_bits) return TSX_HIP_EINVAL;  // TSXHashMap.h:91-94, on the whole (sharded) table
     TableParams &p = m->p;
     p.k = k; p.l = l; p.n = 2 * k; p.wk = (2 * k + 63) / 64;
+    p.lg = l + shard_bits; p.shard = (uint32_t)shard_index;
     p.R = std::min(l, 8);
-    p.F = 2 * k - l;
+    p.F = 2 * k - p.lg;
     const int KB = p.R + p.F;
     int W, C;
     if (s == 0) {
@@ -214,6 +217,7 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l) {
     if (ol < 4 || ol > 34) return TSX_HIP_EINVAL;
     p.sec_mask = (1ULL << ol) - 1ULL;
     tsx_hip_layout &L = m->lay;
+    L.shard_bits = shard_bits; L.shard_index = shard_index;
     L.k = k; L.l = l; L.key_limbs = p.wk; L.entry_limbs = W; L.func_bits = p.F; L.reprobe_bits = p.R;
     L.count_bits = C; L.overflow_l = ol; L.max_reprobes = p.max_reprobes; L.slots = 1ULL << l;
     L.table_bytes = L.slots * (uint64_t)W * 8ULL;
@@ -222,10 +226,15 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l) {
 
 extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
                               uint64_t hash_seed, int device) {
+    return tsx_hip_create_shard(out, k, l, storagebits, overflow_l, hash_seed, device, 0, 0);
+}
+
+extern "C" int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
+                                    uint64_t hash_seed, int device, int shard_bits, int shard_index) {
     if (!out) return TSX_HIP_EINVAL;
     *out = nullptr;
     tsx_hip_map *m = new tsx_hip_map();
-    int rc = derive_layout(m, k, l, storagebits, overflow_l);
+    int rc = derive_layout(m, k, l, storagebits, overflow_l, shard_bits, shard_index);
     if (rc != TSX_HIP_OK) { delete m; return rc; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -238,7 +247,7 @@ extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, 
     if (const char *e = getenv("TSX_HIP_PATH")) m->path = atoi(e);
     if (const char *e = getenv("TSX_HIP_PIECE_BYTES")) {
         const long long v = atoll(e);
-        if (v >= 256) m->piece = ((size_t)v + 15) & ~(size_t)15;
+        if (v >= 256) { m->piece = ((size_t)v + 15) & ~(size_t)15; m->piece_fixed = true; }
     }
     auto fail = [&](int code) { tsx_hip_destroy(m); return code; };
 #define HIP_TRY_C(expr)                                                         \
@@ -249,6 +258,12 @@ extern "C" int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, 
             return fail(_e == hipErrorOutOfMemory ? TSX_HIP_ENOMEM : TSX_HIP_EHIP); \
         }                                                                       \
     } while (0)
+    // Host pieces large enough for the partitioned path to pay off (text >= table / 32),
+    // between 64 MiB and 1 GiB of pinned staging per buffer.
+    if (!m->piece_fixed) {
+        const size_t want = (size_t)(m->lay.table_bytes / 16);
+        m->piece = std::min<size_t>((size_t)1 << 30, std::max<size_t>(STAGE_PIECE_DEFAULT, want)) & ~(size_t)4095;
+    }
     HIP_TRY_C(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY_C(hipGetDeviceProperties(&prop, device));
@@ -344,11 +359,145 @@ static inline int grid_for(const tsx_hip_map *m, uint64_t work_items, int per_cu
         default: { constexpr int WKV = 4; CALL; } break; \
     }
 
+// ---- partitioned path: plan, scratch, launches ------------------------------------
+struct PartPlan {
+    int g;                       // regions of the key log (= scan workgroups, or cuts of a received array)
+    uint64_t log_cap;            // keys per log region
+    int b1, b2;                  // radix bits of level 1 / level 2 (b2 == 0: one level)
+    uint32_t nb1, nb2, nseg, cpr2;
+    uint64_t cap_sub;            // keys per level-2 sub-list
+    uint32_t hist_nb;            // bins of the scan-side histogram (nb1, or #owners for a sharded scan)
+    unsigned long long *c_log, *c_rstart, *c_bstart, *c_bcnt, *c_seg, *d_offs;
+    uint32_t *d_hist;
+    size_t cnt_need;
+};
+
+static bool can_partition(const tsx_hip_map *m) {
+    const TableParams &p = m->p;
+    const int nsegbits = p.l - p.S;
+    return p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 16;  // two levels of <= 256 lists
+}
+
+template <typename T>
+static int grow(hipStream_t st, T *&ptr, size_t &have, size_t need) {
+    if (need <= have) return TSX_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ptr) HIP_TRY(hipFree(ptr));
+    ptr = nullptr; have = 0;
+    HIP_TRY(hipMalloc((void **)&ptr, need + need / 8 + 4096));
+    have = need + need / 8 + 4096;
+    return TSX_HIP_OK;
+}
+
+// maxrec: upper bound of keys; g: number of source regions; own_log: the keys come from
+// this map's scan kernel (needs the log buffer); hist_nb_override: sharded scan.
+static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, uint32_t hist_nb_override,
+                          hipStream_t st, PartPlan &pl) {
+    const TableParams &p = m->p;
+    const int nsegbits = p.l - p.S;
+    pl.g = g;
+    pl.nseg = 1u << nsegbits;
+    // level-1 fan-out is capped at 256 (the scan kernel keeps that histogram in LDS)
+    pl.b1 = std::min(8, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
+    pl.b2 = nsegbits - pl.b1;
+    pl.nb1 = 1u << pl.b1; pl.nb2 = 1u << pl.b2;
+    pl.hist_nb = hist_nb_override ? hist_nb_override : pl.nb1;
+    auto even = [](uint64_t v) { return (v + 1) & ~1ULL; };
+    pl.log_cap = even(maxrec / g + maxrec / g / 3 + 2048);
+    // level 2 runs cpr2 workgroups per level-1 bucket; each owns one sub-list per segment
+    pl.cpr2 = pl.b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / pl.nb1)) : 1;
+    if (pl.b2) if (const char *e = getenv("TSX_HIP_CPR2")) pl.cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
+    const uint64_t per_sub = maxrec / pl.nseg / pl.cpr2;
+    pl.cap_sub = even(per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64);
+    // buffer 0: key log, later the segment sub-lists of a two-level split; buffer 1: packed level-1 output
+    const uint64_t keys_cap = own_log ? (uint64_t)g * pl.log_cap : maxrec;
+    const size_t need0 = std::max<uint64_t>(own_log ? keys_cap : 0, pl.b2 ? (uint64_t)pl.nseg * pl.cpr2 * pl.cap_sub : 0) * 8;
+    const size_t need1 = keys_cap * 8;
+    int rc = grow(st, m->d_buf[0], m->buf_bytes[0], need0);
+    if (rc != TSX_HIP_OK) return rc;
+    rc = grow(st, m->d_buf[1], m->buf_bytes[1], need1);
+    if (rc != TSX_HIP_OK) return rc;
+    // counters: [region fill | region start | bucket start | bucket size | sub-list size], then the
+    // histogram matrix (u32) and its exclusive scan (u64), both max(nb1, hist_nb) x g
+    const uint32_t hb = std::max(pl.nb1, pl.hist_nb);
+    pl.cnt_need = 2 * (size_t)g + 2 * (size_t)hb + (size_t)pl.nseg * pl.cpr2;
+    const size_t mat = (size_t)hb * g;
+    size_t have = m->cnt_entries;
+    unsigned long long *ptr = m->d_cnt;
+    rc = grow(st, ptr, have, pl.cnt_need * 8 + mat * 12 + 64);
+    m->d_cnt = ptr; m->cnt_entries = have;
+    if (rc != TSX_HIP_OK) return rc;
+    pl.c_log = m->d_cnt;                    // fill of each log region, or size of each cut of a received array
+    pl.c_rstart = pl.c_log + g;
+    pl.c_bstart = pl.c_rstart + g; pl.c_bcnt = pl.c_bstart + hb; pl.c_seg = pl.c_bcnt + hb;
+    pl.d_offs = pl.c_seg + (size_t)pl.nseg * pl.cpr2;
+    pl.d_hist = reinterpret_cast<uint32_t *>(pl.d_offs + mat);
+    HIP_TRY(hipMemsetAsync(m->d_cnt, 0, pl.cnt_need * 8, st));
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
+        attr_done = true;
+    }
+    return TSX_HIP_OK;
+}
+
+// Radix level 1 (+ level 2) and the segment build.  Source keys: g regions of `src`,
+// either src_cap apart with fills c_log (a key log) or at region_start/c_log (cuts of a
+// packed array); pl.d_hist must hold their level-1 histogram.
+static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_t *src,
+                               const unsigned long long *region_start, uint64_t src_cap, hipStream_t st) {
+    const TableParams &p = m->p;
+    // ring depth: 7 keys may stay behind a flush, plus one batch's arrivals (mean = batch / nb)
+    auto ring_bits = [](uint32_t nb) {
+        const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_RPT / nb);
+        uint32_t bits = 4;
+        while ((1u << bits) < 8 + 2 * mean && bits < 6) ++bits;
+        return bits;
+    };
+    auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 32); };
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs, pl.nb1,
+                       (uint32_t)pl.g, pl.c_bstart, pl.c_bcnt);
+    {   // level 1: every region -> packed array ordered by the top b1 bits of the home slot
+        const uint32_t bits = ring_bits(pl.nb1);
+        hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st, m->p, src,
+                           region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u, m->d_buf[1],
+                           (const unsigned long long *)pl.d_offs, (unsigned long long *)nullptr, (uint64_t)0, pl.nb1,
+                           (uint32_t)(p.l - pl.b1), bits);
+        HIP_TRY(hipGetLastError());
+    }
+    const uint64_t *lists = m->d_buf[1];
+    const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
+    uint64_t lists_cap = 0;
+    uint32_t pieces = 1;
+    if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
+        const uint32_t bits = ring_bits(pl.nb2);
+        hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.nb1 * pl.cpr2), dim3(PART_NT), part_lds(pl.nb2, bits), st, m->p,
+                           (const uint64_t *)m->d_buf[1], (const unsigned long long *)pl.c_bstart,
+                           (const unsigned long long *)pl.c_bcnt, (uint64_t)0, pl.nb1, pl.cpr2, m->d_buf[0],
+                           (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits);
+        HIP_TRY(hipGetLastError());
+        lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
+    }
+    if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
+        const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 4);
+        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_start,
+                           lists_cnt, lists_cap, pieces, pl.nseg, m->dbg);
+        HIP_TRY(hipGetLastError());
+    }
+    return TSX_HIP_OK;
+}
+
+struct HotOut { uint64_t *keys = nullptr, *cnts = nullptr; uint64_t cap = 0; unsigned long long *n = nullptr; };
+
 // One FASTQ piece already on the device: passes 1-3.  own_end = number of start
 // positions this piece owns (bytes past it are halo for windows that begin
 // before it); head_open = the piece starts in the middle of a line.
+// shard_send != nullptr: sharded scan -- the keys are not built into the local table but
+// split by owner into shard_send (counts per owner to shard_counts), hot keys to `hot`.
 static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
-                           hipStream_t st) {
+                           hipStream_t st, uint64_t *shard_send = nullptr, uint64_t shard_cap = 0,
+                           unsigned long long *shard_counts = nullptr, HotOut hot = HotOut()) {
     if (own_end == 0) return TSX_HIP_OK;
     const uint64_t ntiles = (own_end + TILE - 1) / TILE;
     if (ntiles > m->tile_cap) {
@@ -374,112 +523,113 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     // Which insert path?  The partitioned path rewrites every touched segment
     // once (2 x table bytes at worst), the atomic path pays ~60 ps per k-mer.
     const TableParams &p = m->p;
-    const int nsegbits = p.l - p.S;
-    const bool can_part = (p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 16);  // two levels of <= 256 lists
-    const bool use_part = can_part && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes));
+    const bool use_part = shard_send || (can_partition(m) && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes)));
     if (!use_part) {
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
                                           own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg,
                                           (uint64_t *)nullptr, (uint64_t)0, (unsigned long long *)nullptr,
-                                          (uint32_t *)nullptr, 0u, 0u));
+                                          (uint32_t *)nullptr, 0u, 0u, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                          (uint64_t)0, (unsigned long long *)nullptr));
         HIP_TRY(hipGetLastError());
         if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
         return TSX_HIP_OK;
     }
 
     const uint64_t maxrec = own_end / 2 + 65536;
-    const uint32_t nseg = 1u << nsegbits;
-    // level-1 fan-out is capped at 256 (the scan kernel keeps that histogram in LDS)
-    const int b1 = std::min(8, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2), b2 = nsegbits - b1;
-    const uint32_t nb1 = 1u << b1, nb2 = 1u << b2;
-    auto even = [](uint64_t v) { return (v + 1) & ~1ULL; };
-    const uint64_t log_cap = even(maxrec / g3 + maxrec / g3 / 3 + 2048);
-    // level 2 runs cpr2 workgroups per level-1 bucket; each owns one sub-list per segment
-    uint32_t cpr2 = b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / nb1)) : 1;
-    if (b2) if (const char *e = getenv("TSX_HIP_CPR2")) cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
-    const uint64_t per_sub = maxrec / nseg / cpr2;
-    const uint64_t cap_sub = even(per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64);
-    const uint64_t cap_seg = cap_sub * cpr2;
-    // buffer 0: key log, later the segment lists of a two-level split; buffer 1: level-1 lists
-    const size_t need0 = std::max<uint64_t>((uint64_t)g3 * log_cap, b2 ? (uint64_t)nseg * cap_seg : 0) * 8;
-    const size_t need1 = (uint64_t)g3 * log_cap * 8;  // packed level-1 output: never more keys than the log
-    const size_t need[2] = {need0, need1};
-    for (int i = 0; i < 2; ++i)
-        if (need[i] > m->buf_bytes[i]) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (m->d_buf[i]) HIP_TRY(hipFree(m->d_buf[i]));
-            m->d_buf[i] = nullptr; m->buf_bytes[i] = 0;
-            HIP_TRY(hipMalloc((void **)&m->d_buf[i], need[i] + need[i] / 8));
-            m->buf_bytes[i] = need[i] + need[i] / 8;
-        }
-    // counters: [log fill per workgroup | level-1 bucket start | level-1 bucket size | segment list size]
-    // then the level-1 histogram matrix (u32) and its exclusive scan (u64), both nb1 x g3
-    const size_t cnt_need = (size_t)g3 + 2 * (size_t)nb1 + (size_t)nseg * cpr2;
-    const size_t mat = (size_t)nb1 * g3;
-    const size_t cnt_bytes = cnt_need * 8 + mat * 8 + mat * 4 + 64;
-    if (cnt_bytes > m->cnt_entries) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (m->d_cnt) HIP_TRY(hipFree(m->d_cnt));
-        m->d_cnt = nullptr; m->cnt_entries = 0;
-        HIP_TRY(hipMalloc((void **)&m->d_cnt, cnt_bytes + 4096));
-        m->cnt_entries = cnt_bytes + 4096;
-    }
-    unsigned long long *c_log = m->d_cnt, *c_bstart = c_log + g3, *c_bcnt = c_bstart + nb1, *c_seg = c_bcnt + nb1;
-    unsigned long long *d_offs = c_seg + (size_t)nseg * cpr2;
-    uint32_t *d_hist = reinterpret_cast<uint32_t *>(d_offs + mat);
-    HIP_TRY(hipMemsetAsync(m->d_cnt, 0, cnt_need * 8, st));
-
+    const uint32_t nown = 1u << (p.lg - p.l);
+    PartPlan pl;
+    int rc = plan_partition(m, maxrec, g3, true, shard_send ? nown : 0, st, pl);
+    if (rc != TSX_HIP_OK) return rc;
+    // scan -> key log (one region per workgroup) + histogram by level-1 bucket, or by owner GPU
     hipLaunchKernelGGL((count_fastq_kernel<1>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n, own_end,
-                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], log_cap, c_log, d_hist, nb1,
-                       (uint32_t)(p.l - b1));
+                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
+                       shard_send ? nown : pl.nb1, (uint32_t)(shard_send ? p.l : p.l - pl.b1), hot.keys, hot.cnts, hot.cap,
+                       hot.n);
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[2], st));
-
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
-        attr_done = true;
-    }
-    // ring depth: 7 keys may stay behind a flush, plus one batch's arrivals (mean = batch / nb)
-    auto ring_bits = [](uint32_t nb) {
-        const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_RPT / nb);
-        uint32_t bits = 4;
-        while ((1u << bits) < 8 + 2 * mean && bits < 6) ++bits;
-        return bits;
-    };
-    auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 32); };
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)d_hist, d_offs, nb1, (uint32_t)g3,
-                       c_bstart, c_bcnt);
-    {   // level 1: every workgroup's key log -> packed array ordered by the top b1 bits of the home slot
-        const uint32_t bits = ring_bits(nb1);
-        hipLaunchKernelGGL(partition_ring_kernel, dim3(g3), dim3(PART_NT), part_lds(nb1, bits), st, m->p,
-                           (const uint64_t *)m->d_buf[0], (const unsigned long long *)nullptr,
-                           (const unsigned long long *)c_log, log_cap, (uint32_t)g3, 1u, m->d_buf[1],
-                           (const unsigned long long *)d_offs, (unsigned long long *)nullptr, (uint64_t)0, nb1,
-                           (uint32_t)(p.l - b1), bits);
+    if (shard_send) {
+        // level 0: split every log region by owner into the caller's send buffer (exact offsets)
+        if ((uint64_t)g3 * pl.log_cap > shard_cap) return TSX_HIP_ERANGE;
+        hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs, nown,
+                           (uint32_t)g3, pl.c_bstart, pl.c_bcnt);
+        hipLaunchKernelGGL(split_owner_kernel, dim3(g3), dim3(PART_NT), 0, st, (const uint64_t *)m->d_buf[0],
+                           (const unsigned long long *)pl.c_log, pl.log_cap, (uint32_t)g3, shard_send,
+                           (const unsigned long long *)pl.d_offs, nown, (uint32_t)p.l);
         HIP_TRY(hipGetLastError());
-    }
-    const uint64_t *lists = m->d_buf[1];
-    const unsigned long long *lists_start = c_bstart, *lists_cnt = c_bcnt;
-    uint64_t lists_cap = 0;
-    uint32_t pieces = 1;
-    if (b2) {  // level 2: cpr workgroups per level-1 bucket, each with its own sub-list per segment
-        const uint32_t bits = ring_bits(nb2);
-        hipLaunchKernelGGL(partition_ring_kernel, dim3(nb1 * cpr2), dim3(PART_NT), part_lds(nb2, bits), st, m->p,
-                           (const uint64_t *)m->d_buf[1], (const unsigned long long *)c_bstart,
-                           (const unsigned long long *)c_bcnt, (uint64_t)0, nb1, cpr2, m->d_buf[0],
-                           (const unsigned long long *)nullptr, c_seg, cap_sub, nb2, (uint32_t)p.S, bits);
-        HIP_TRY(hipGetLastError());
-        lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = c_seg; lists_cap = cap_sub; pieces = cpr2;
-    }
-    if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
-        const int gb = (int)std::min<uint32_t>(nseg, (uint32_t)m->cus * 4);
-        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_start,
-                           lists_cnt, lists_cap, pieces, nseg, m->dbg);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(shard_counts, pl.c_bcnt, nown * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+    } else {
+        rc = run_partition_build(m, pl, m->d_buf[0], nullptr, pl.log_cap, st);
+        if (rc != TSX_HIP_OK) return rc;
     }
     if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, size_t n, void *dev_send,
+                                         size_t send_cap_keys, void *dev_send_counts, void *dev_hot_keys,
+                                         void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *stream) {
+    if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15) || !dev_send || !dev_send_counts || !dev_hot_keys ||
+        !dev_hot_counts || !dev_hot_n)
+        return TSX_HIP_EINVAL;
+    if (m->p.wk != 1 || m->p.W != 1) return TSX_HIP_EINVAL;  // one-limb keys only (k <= 32)
+    if (n >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;        // one window per call
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(dev_hot_n, 0, 8, st));
+    HIP_TRY(hipMemsetAsync(dev_send_counts, 0, sizeof(unsigned long long) << (m->p.lg - m->p.l), st));
+    if (n == 0) return TSX_HIP_OK;
+    HotOut hot;
+    hot.keys = (uint64_t *)dev_hot_keys; hot.cnts = (uint64_t *)dev_hot_counts; hot.cap = hot_cap;
+    hot.n = (unsigned long long *)dev_hot_n;
+    return run_fastq_piece(m, (const uint8_t *)dev_text, n, n, 0, st, (uint64_t *)dev_send, send_cap_keys,
+                           (unsigned long long *)dev_send_counts, hot);
+}
+
+extern "C" int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, size_t *keys_out) {
+    if (!m || !keys_out) return TSX_HIP_EINVAL;
+    const uint64_t ntiles = (text_bytes + TILE - 1) / TILE;
+    const int g3 = (int)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3));
+    const uint64_t maxrec = text_bytes / 2 + 65536;
+    const uint64_t log_cap = (maxrec / g3 + maxrec / g3 / 3 + 2048 + 1) & ~1ULL;
+    *keys_out = (size_t)g3 * log_cap;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *stream) {
+    if (!m || (!dev_keys && n_keys) || ((uintptr_t)dev_keys & 7)) return TSX_HIP_EINVAL;
+    if (n_keys == 0) return TSX_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    if (!can_partition(m)) {  // tiny tables: plain atomic inserts of the hashed keys
+        const int grid = grid_for(m, n_keys, 8);
+        hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
+                           (const uint64_t *)nullptr, (uint64_t)n_keys);
+        HIP_TRY(hipGetLastError());
+        return TSX_HIP_OK;
+    }
+    const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_keys + 4095) / 4096, (uint64_t)m->cus * 3));
+    PartPlan pl;
+    int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl);
+    if (rc != TSX_HIP_OK) return rc;
+    const uint64_t region_len = (n_keys + g - 1) / g;
+    hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, (const uint64_t *)dev_keys, (uint64_t)n_keys, region_len,
+                       (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1), pl.d_hist, pl.c_rstart, pl.c_log);
+    HIP_TRY(hipGetLastError());
+    return run_partition_build(m, pl, (const uint64_t *)dev_keys, pl.c_rstart, 0, st);
+}
+
+extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
+                                         void *stream) {
+    if (!m || (!dev_keys && n)) return TSX_HIP_EINVAL;
+    if (m->p.wk != 1 || m->p.W != 1) return TSX_HIP_EINVAL;
+    if (n == 0) return TSX_HIP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    const int grid = grid_for(m, n, 8);
+    hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
+                       (const uint64_t *)dev_counts, (uint64_t)n);
+    HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
 
@@ -546,9 +696,15 @@ extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, 
     return TSX_HIP_OK;
 }
 
-static int ensure_staging(tsx_hip_map *m) {
-    if (m->stage_bytes) return TSX_HIP_OK;
-    const size_t bytes = m->piece + STAGE_PAD;
+static int ensure_staging(tsx_hip_map *m, size_t n) {
+    const size_t bytes = std::min(m->piece, n) + STAGE_PAD + 128;
+    if (m->stage_bytes >= bytes) return TSX_HIP_OK;
+    for (int i = 0; i < 2; ++i) {  // grow: drop the smaller buffers first
+        if (m->h_stage[i]) { HIP_TRY(hipHostFree(m->h_stage[i])); m->h_stage[i] = nullptr; }
+        if (m->d_stage[i]) { HIP_TRY(hipFree(m->d_stage[i])); m->d_stage[i] = nullptr; }
+        if (m->stage_done[i]) { HIP_TRY(hipEventDestroy(m->stage_done[i])); m->stage_done[i] = nullptr; }
+    }
+    m->stage_bytes = 0;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipHostMalloc((void **)&m->h_stage[i], bytes, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&m->d_stage[i], bytes));
@@ -561,7 +717,8 @@ static int ensure_staging(tsx_hip_map *m) {
 extern "C" int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n) {
     if (!m || (!text && n)) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
-    int rc = ensure_staging(m);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    int rc = ensure_staging(m, n);
     if (rc != TSX_HIP_OK) return rc;
     hipStream_t st = m->stream;
     HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));

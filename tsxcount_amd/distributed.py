@@ -71,3 +71,89 @@ def merge_tables(hmap, group=None):
                                                   ctypes.c_void_p(recv_c.data_ptr()), recv_k.shape[0], None))
     hmap.sync()
     return int(recv_k.shape[0])
+
+
+class ShardedCounter:
+    """Multi-GPU counting into ONE table sharded by slot range (k <= 32).
+
+    Rank r holds home slots [r << l, (r+1) << l) of a table with 2^(l + log2 world)
+    slots (TSXHashMapHIP(..., shard_bits=log2 world, shard_index=r)).  Every rank
+    scans its own reads; the hashed keys travel to their owners through ONE
+    all-to-all BEFORE they are built into a table, so nothing is inserted twice and
+    no table is torn down and re-inserted (merge_tables() does that).  Hot k-mers
+    that the scan merged on chip travel as a small (key, count) list through an
+    all-gather.  After step() rank r answers getKmerCount for the k-mers it owns.
+    """
+
+    HOT_CAP = 1 << 20
+
+    def __init__(self, hmap, max_text_bytes, group=None):
+        from . import _check
+        self.m, self.group = hmap, group
+        self.world = dist.get_world_size(group)
+        assert self.world == 1 << hmap.layout.shard_bits, "world size must equal 2^shard_bits"
+        self.dev = torch.device("cuda", hmap.device)
+        cap = ctypes.c_size_t(0)
+        _check(hmap._lib.tsx_hip_shard_send_capacity(hmap.handle, max_text_bytes, ctypes.byref(cap)))
+        self.send = torch.empty((cap.value,), dtype=torch.int64, device=self.dev)
+        self.counts = torch.zeros((self.world,), dtype=torch.int64, device=self.dev)
+        self.hot_k = torch.zeros((self.HOT_CAP,), dtype=torch.int64, device=self.dev)
+        self.hot_c = torch.zeros((self.HOT_CAP,), dtype=torch.int64, device=self.dev)
+        self.hot_n = torch.zeros((1,), dtype=torch.int64, device=self.dev)
+        self.recv = torch.empty((0,), dtype=torch.int64, device=self.dev)
+        self.gloo = dist.get_backend(group) == "gloo"
+
+    def _a2a(self, out, inp, out_sizes=None, in_sizes=None):
+        if self.gloo:  # CPU collective (tests: several ranks sharing one GPU)
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_sizes, input_split_sizes=in_sizes,
+                                   group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, output_split_sizes=out_sizes, input_split_sizes=in_sizes,
+                                   group=self.group)
+
+    def step(self, text_ptr, nbytes):
+        """Count one FASTQ text (device pointer) of this rank's reads into the sharded table."""
+        from . import _check
+        m, L = self.m, self.m._lib
+        vp = ctypes.c_void_p
+        _check(L.tsx_hip_shard_scan_device(m.handle, vp(text_ptr), nbytes, vp(self.send.data_ptr()),
+                                           self.send.numel(), vp(self.counts.data_ptr()), vp(self.hot_k.data_ptr()),
+                                           vp(self.hot_c.data_ptr()), self.HOT_CAP, vp(self.hot_n.data_ptr()), None))
+        torch.cuda.synchronize(self.dev)
+        ss = [int(x) for x in self.counts.tolist()]
+        recv_sizes = torch.empty_like(self.counts)
+        self._a2a(recv_sizes, self.counts)
+        rs = [int(x) for x in recv_sizes.tolist()]
+        n_recv = sum(rs)
+        if self.recv.numel() < n_recv:
+            self.recv = torch.empty((n_recv + n_recv // 8 + 1024,), dtype=torch.int64, device=self.dev)
+        self._a2a(self.recv[:n_recv], self.send[:sum(ss)], rs, ss)
+        # hot (key, count) lists: pad to the longest, gather everywhere, owners pick theirs
+        nh = torch.tensor([min(int(self.hot_n.item()), self.HOT_CAP)], dtype=torch.int64,
+                          device="cpu" if self.gloo else self.dev)
+        dist.all_reduce(nh, op=dist.ReduceOp.MAX, group=self.group)
+        nh = int(nh.item())
+        hk = hc = None
+        if nh:
+            mine = min(int(self.hot_n.item()), self.HOT_CAP)
+            self.hot_c[mine:nh].zero_()   # entries past this rank's own list carry count 0 = ignored
+            src_k, src_c = self.hot_k[:nh], self.hot_c[:nh]
+            if self.gloo:
+                gk = [torch.empty((nh,), dtype=torch.int64) for _ in range(self.world)]
+                gc = [torch.empty((nh,), dtype=torch.int64) for _ in range(self.world)]
+                dist.all_gather(gk, src_k.cpu(), group=self.group)
+                dist.all_gather(gc, src_c.cpu(), group=self.group)
+                hk, hc = torch.cat(gk).to(self.dev), torch.cat(gc).to(self.dev)
+            else:
+                hk = torch.empty((nh * self.world,), dtype=torch.int64, device=self.dev)
+                hc = torch.empty((nh * self.world,), dtype=torch.int64, device=self.dev)
+                dist.all_gather_into_tensor(hk, src_k.contiguous(), group=self.group)
+                dist.all_gather_into_tensor(hc, src_c.contiguous(), group=self.group)
+        torch.cuda.synchronize(self.dev)
+        _check(L.tsx_hip_shard_build_device(m.handle, vp(self.recv.data_ptr()), n_recv, None))
+        if nh:
+            _check(L.tsx_hip_add_hashed_device(m.handle, vp(hk.data_ptr()), vp(hc.data_ptr()), hk.numel(), None))
+        m.sync()
+        return n_recv
