@@ -80,10 +80,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--l", type=int, default=30, help="log2 table slots per GPU (load factor 0.75 at the default input)")
+    ap.add_argument("--l", "--table-bits", dest="l", type=int, default=30, help="log2 table slots per GPU (load factor 0.75 at the default input)")
     ap.add_argument("--reads", type=int, default=1087000, help="synthetic reads per GPU (~1e9 k-mers at k=31)")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--path", default="auto", choices=["auto", "atomic", "partitioned"])
+    ap.add_argument("--merge", default="shard", choices=["shard", "tables"],
+                    help="N > 1: exchange keys before the build (sharded table) or merge per-GPU tables after it")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (one GPU per rank); gloo only to rehearse N > 1 on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,11 +102,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red = torch.device("cpu") if args.backend == "gloo" else dev  # where the tiny reductions live
 
     # synthetic input straight into HBM; every rank owns its own read shard
     first = rank * args.reads
@@ -111,16 +118,25 @@ def main():
     torch.cuda.synchronize(dev)
     T.synth_fastq_device(args.seed, first, args.reads, args.k, text.data_ptr(), nbytes, device=local_rank)
 
-    m = T.TSXHashMapHIP(args.l, 0, args.k, device=local_rank)
+    # N > 1: ONE table sharded by slot range over the GPUs (2^(l + log2 N) slots in all, so the
+    # load factor per GPU is the same at every N: weak scaling).  Keys travel to their owner
+    # through one RCCL all-to-all before they are built; see tsxcount_amd/distributed.py.
+    sharded = world > 1 and (world & (world - 1)) == 0 and args.k <= 32 and args.merge == "shard"
+    bits = world.bit_length() - 1 if sharded else 0
+    m = T.TSXHashMapHIP(args.l, 0, args.k, device=local_rank, shard_bits=bits, shard_index=rank if sharded else 0)
     m.set_path(args.path)
+    sc = TD.ShardedCounter(m, nbytes) if sharded else None
 
     def step():
         m.clear()
-        m.countFastqDevice(text.data_ptr(), nbytes)
-        if world > 1:
-            TD.merge_tables(m)
+        if sharded:
+            sc.step(text.data_ptr(), nbytes)
         else:
-            m.sync()
+            m.countFastqDevice(text.data_ptr(), nbytes)
+            if world > 1:
+                TD.merge_tables(m)  # per-GPU tables merged afterwards (any N, any k)
+            else:
+                m.sync()
 
     for _ in range(args.warmup):
         step()
@@ -140,10 +156,10 @@ def main():
 
     # max over ranks
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        kt = torch.tensor([kmers_rank], dtype=torch.int64, device=dev)
+        kt = torch.tensor([kmers_rank], dtype=torch.int64, device=red)
         dist.all_reduce(kt, op=dist.ReduceOp.SUM)
         kmers_total = int(kt.item())
     else:
@@ -151,8 +167,14 @@ def main():
 
     st = m.stats()
     check_ok = (st["insert_failures"] == 0 and st["overflow_failures"] == 0 and st["lock_timeouts"] == 0)
-    if world == 1:
-        check_ok = check_ok and st["kmers_added"] == kmers_rank
+    if world == 1 or sharded:
+        check_ok = check_ok and st["kmers_added"] == kmers_rank  # every k-mer of this rank's reads was scanned
+    if world > 1:
+        # every distinct k-mer ends up on exactly one rank; their number is the same whichever way the
+        # reads were spread, and (almost) every non-polyA k-mer of this generator is unique
+        dsum = torch.tensor([st["distinct"]], dtype=torch.int64, device=red)
+        dist.all_reduce(dsum, op=dist.ReduceOp.SUM)
+        check_ok = check_ok and 0.75 * kmers_total < int(dsum.item()) < kmers_total
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -188,7 +210,8 @@ def main():
                                    "k=%d, table 2^%d slots/GPU, %s insert path%s"
                                    % (args.reads, kmers_rank, args.k, args.l,
                                       "partitioned" if partitioned else "atomic",
-                                      ", per-GPU tables merged over RCCL all-to-all" if world > 1 else ""),
+                                      (", table sharded by slot range, keys exchanged by one RCCL all-to-all" if sharded
+                                       else ", per-GPU tables merged over RCCL all-to-all") if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
                        "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL"},
             "roofline": {"bound": "hbm", "kernel": "count_fastq_kernel<1>", "achieved": achieved,
