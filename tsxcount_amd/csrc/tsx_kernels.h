@@ -374,6 +374,158 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     }
 }
 
+// Pass 3 of the partitioned path (k <= 32): scan -> 2-bit encode -> hash -> key log.
+// Same tile front end as count_fastq_kernel; what differs is what happens to a k-mer:
+//   * nothing is inserted and nothing is deduplicated per workgroup -- duplicates are
+//     summed where they meet anyway, in the LDS segment build;
+//   * every WAVE owns a region of the key log, so a run of keys is appended with one
+//     ballot and scalar arithmetic: no atomics, no workgroup barrier inside the
+//     position loop (two barriers per 4 KiB tile in all);
+//   * equal neighbours are still run-length merged across the wave; a run longer than
+//     one (homopolymer tails) goes to the wave's 8-entry hot cache with its length;
+//   * the level-1 histogram of each region is kept in LDS (exact offsets downstream).
+// Regions and histogram columns are indexed by blockIdx.x * 4 + wave.
+__global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const uint8_t *buf, uint64_t n,
+                                                         uint64_t own_end, int head_open, const uint32_t *tile_line,
+                                                         uint64_t ntiles, int dbg, uint64_t *log, uint64_t log_cap,
+                                                         unsigned long long *log_cnt, uint32_t *hist, uint32_t hist_nb,
+                                                         uint32_t hist_shift, uint64_t *hot_keys, uint64_t *hot_cnts,
+                                                         uint64_t hot_cap, unsigned long long *hot_n) {
+    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
+    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
+    __shared__ uint64_t s_le[TILE / 64];
+    __shared__ uint8_t s_lb[TILE / 16];
+    __shared__ uint32_t s_wsum[NT / 64];
+    constexpr int HOT_N = 8;
+    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hist[(NT / 64) * 256];
+    extern __shared__ uint64_t s_lut[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lut_words = p.groups * (1 << p.g);
+    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
+    for (int i = tid; i < (NT / 64) * 256; i += NT) s_hist[i] = 0;
+    if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
+    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
+    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
+    unsigned long long added = 0;
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t need = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
+    uint64_t *my_log = log + (uint64_t)region * log_cap;
+    uint32_t *my_hist = s_hist + wave * 256;
+    uint32_t fill = 0;  // wave-uniform
+
+    auto side_insert = [&](uint64_t hkey, uint64_t d) {
+        if (dbg & 1) return;
+        if (hot_keys) {  // sharded table: the key may belong to another GPU
+            const unsigned long long at = atomicAdd(hot_n, 1ULL);
+            if (at < hot_cap) { hot_keys[at] = hkey; hot_cnts[at] = d; }
+            else atomicAdd(&p.stats[ST_FAIL], (unsigned long long)d);
+        } else {
+            const uint64_t h1[1] = {hkey};
+            insert_key<1>(p, h1, d);
+        }
+    };
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * TILE;
+        lds_barrier();  // previous tile's LDS fully consumed
+        {
+            const uint64_t off = base + (uint64_t)tid * 16;
+            uint32_t nl, le, code;
+            classify16(load16(buf, off, n), prev_is_nl(buf, off, n, head_open), nl, le, code);
+            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
+            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
+            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
+            if (tid < HALO / 16) {
+                const uint64_t hoff = base + TILE + (uint64_t)tid * 16;
+                uint32_t hnl, hle, hcode;
+                classify16(load16(buf, hoff, n), false, hnl, hle, hcode);
+                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
+                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
+            }
+            const uint32_t c = __popc(le);
+            const uint32_t inc = wave_incl_scan(c);
+            if (lane == 63) s_wsum[wave] = inc;
+            lds_barrier();
+            uint32_t woff = tile_line[tile];
+            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        lds_barrier();
+
+        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
+#pragma unroll 4
+        for (int it = 0; it < TILE / NT; ++it) {
+            const uint32_t pp = (uint32_t)(it * NT + tid);
+            const uint64_t gpos = base + pp;
+            // line index of this byte: group base + line ends before it in the group
+            const uint32_t grp = pp >> 4;
+            const uint32_t le_before = reinterpret_cast<const uint16_t *>(s_le)[grp] & ((1u << (pp & 15)) - 1u);
+            const uint32_t line = (uint32_t)s_lb[grp] + __popc(le_before);
+            // no newline inside [pp, pp+k), k <= 32: one 32-bit funnel shift of the newline mask
+            const uint32_t w = pp >> 5, o = pp & 31;
+            const uint32_t win = __funnelshift_r(nl32[w], nl32[w + 1], o);
+            const bool valid = ((line & 3u) == 1u) && ((win & need) == 0u) && (gpos + k <= n) && (gpos < own_end);
+            // header, '+' and quality lines are half of a FASTQ text: skip waves without a k-mer start
+            if (__ballot(valid) == 0ULL) continue;
+            uint64_t x[1];
+            extract_kmer<1>(s_codes, pp, p.top_mask, x);
+            // run-length merge across the wave: lanes hold consecutive positions
+            const uint64_t xp = __shfl_up((unsigned long long)x[0], 1, 64);
+            const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
+            const bool leader = valid && (lane == 0 || !prev_valid || x[0] != xp);
+            const unsigned long long bnd = __ballot(leader || !valid);
+            const unsigned long long above = (lane == 63) ? 0ULL : (bnd >> (lane + 1));
+            const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)(63 - lane)) + 1u;
+            added += valid ? 1ULL : 0ULL;
+            uint64_t h[1] = {0};
+            if (leader) hash_apply<1>(p, (const uint64_t *)s_lut, x, h);
+            // runs longer than one: fold into the wave's hot cache, one lane at a time
+            unsigned long long hot = __ballot(leader && runlen > 1);
+            while (hot) {
+                const int src = __builtin_ctzll(hot);
+                hot &= hot - 1;
+                if (lane == src) {
+                    uint64_t *hkey = s_hot_key + wave * HOT_N;
+                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                    int at = -1;
+                    for (int q = 0; q < HOT_N; ++q)
+                        if (hcnt[q] && hkey[q] == h[0]) { at = q; break; }
+                    if (at < 0)
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (!hcnt[q]) { at = q; hkey[q] = h[0]; break; }
+                    if (at >= 0 && (uint64_t)hcnt[at] + runlen < 0xFFFFFFF0ULL) hcnt[at] += runlen;
+                    else side_insert(h[0], runlen);
+                }
+            }
+            // single occurrences: one contiguous run of this wave's log region
+            const bool emit = leader && runlen == 1;
+            const unsigned long long mk = __ballot(emit);
+            if (emit) {
+                const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
+                if (at < log_cap) {
+                    my_log[at] = h[0];
+                    atomicAdd(&my_hist[(uint32_t)(h[0] >> hist_shift) & (hist_nb - 1)], 1u);
+                } else {
+                    side_insert(h[0], 1);  // region full: atomic path (or the exchanged list)
+                }
+            }
+            fill += (uint32_t)__builtin_popcountll(mk);
+        }
+    }
+    lds_barrier();
+    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if (lane == 0) {
+        if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        log_cnt[region] = min((uint64_t)fill, log_cap);
+    }
+    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
+}
+
 // addKmer for encoded k-mers already on the device (API batches, merge inserts).
 template <int WK>
 __global__ __launch_bounds__(NT) void add_kmers_kernel(TableParams p, const uint64_t *kmers,

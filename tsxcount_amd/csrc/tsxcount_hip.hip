@@ -28,6 +28,7 @@ static thread_local std::string g_last_error;
         }                                                                                \
     } while (0)
 
+static const int SCAN_WG_PER_CU = 4;  // scan_log_kernel workgroups per CU (LDS 22 KiB, 140 VGPRs)
 static const size_t STAGE_PIECE_DEFAULT = (size_t)64 << 20;  // bytes of FASTQ per host piece
 
 struct tsx_hip_map {
@@ -537,24 +538,27 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
 
     const uint64_t maxrec = own_end / 2 + 65536;
     const uint32_t nown = 1u << (p.lg - p.l);
+    // the scan kernel of this path keeps one log region per WAVE
+    const int gs = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * SCAN_WG_PER_CU);
+    const int greg = gs * (NT / 64);
     PartPlan pl;
-    int rc = plan_partition(m, maxrec, g3, true, shard_send ? nown : 0, st, pl);
+    int rc = plan_partition(m, maxrec, greg, true, shard_send ? nown : 0, st, pl);
     if (rc != TSX_HIP_OK) return rc;
-    // scan -> key log (one region per workgroup) + histogram by level-1 bucket, or by owner GPU
-    hipLaunchKernelGGL((count_fastq_kernel<1>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n, own_end,
-                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
+    // scan -> key log + histogram by level-1 bucket, or by owner GPU for a sharded scan
+    hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, m->p, d_text, n, own_end, head_open,
+                       (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
                        shard_send ? nown : pl.nb1, (uint32_t)(shard_send ? p.l : p.l - pl.b1), hot.keys, hot.cnts, hot.cap,
                        hot.n);
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[2], st));
     if (shard_send) {
         // level 0: split every log region by owner into the caller's send buffer (exact offsets)
-        if ((uint64_t)g3 * pl.log_cap > shard_cap) return TSX_HIP_ERANGE;
+        if ((uint64_t)greg * pl.log_cap > shard_cap) return TSX_HIP_ERANGE;
         hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs, nown,
-                           (uint32_t)g3, pl.c_bstart, pl.c_bcnt);
-        hipLaunchKernelGGL(split_owner_kernel, dim3(g3), dim3(PART_NT), 0, st, (const uint64_t *)m->d_buf[0],
-                           (const unsigned long long *)pl.c_log, pl.log_cap, (uint32_t)g3, shard_send,
-                           (const unsigned long long *)pl.d_offs, nown, (uint32_t)p.l);
+                           (uint32_t)greg, pl.c_bstart, pl.c_bcnt);
+        hipLaunchKernelGGL(split_owner_kernel, dim3(std::min(greg, m->cus * 8)), dim3(PART_NT), 0, st,
+                           (const uint64_t *)m->d_buf[0], (const unsigned long long *)pl.c_log, pl.log_cap,
+                           (uint32_t)greg, shard_send, (const unsigned long long *)pl.d_offs, nown, (uint32_t)p.l);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(shard_counts, pl.c_bcnt, nown * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
     } else {
@@ -589,10 +593,10 @@ extern "C" int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, s
 extern "C" int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, size_t *keys_out) {
     if (!m || !keys_out) return TSX_HIP_EINVAL;
     const uint64_t ntiles = (text_bytes + TILE - 1) / TILE;
-    const int g3 = (int)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3));
+    const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)m->cus * SCAN_WG_PER_CU)) * (NT / 64);
     const uint64_t maxrec = text_bytes / 2 + 65536;
-    const uint64_t log_cap = (maxrec / g3 + maxrec / g3 / 3 + 2048 + 1) & ~1ULL;
-    *keys_out = (size_t)g3 * log_cap;
+    const uint64_t log_cap = (maxrec / g + maxrec / g / 3 + 2048 + 1) & ~1ULL;
+    *keys_out = (size_t)g * log_cap;
     return TSX_HIP_OK;
 }
 
