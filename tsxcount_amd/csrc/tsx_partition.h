@@ -147,7 +147,8 @@ constexpr int PART_ITER = 8;  // lists per octet: nb <= PART_ITER * PART_NT / 8 
 __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
-    unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift, uint32_t capbits) {
+    const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
+    uint32_t capbits) {
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     if (r >= nregions) return;
     for (uint32_t b = tid; b < nb; b += PART_NT) {
         s_tail[b] = 0; s_head[b] = 0;
-        if (offs) { s_cur[b] = offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
+        if (offs) { s_cur[b] = offs_base[b] + offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
         else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap; s_lim[b] = s_cur[b] + dst_cap; }
     }
     lds_barrier();
@@ -262,40 +263,47 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         }
 }
 
-// Exclusive scan of the per-workgroup level-1 histograms hist[b * G + g]
-// (bucket-major) into write offsets, plus start and size of every bucket.
-__global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *hist, unsigned long long *offs, uint32_t nb,
-                                                       uint32_t G, unsigned long long *bucket_start,
-                                                       unsigned long long *bucket_cnt) {
+// Write offsets from the level-1 histograms hist[b * G + g] (bucket-major), two steps:
+//   offsets_rows_kernel    workgroup b: exclusive scan of row b (all regions' keys for
+//                          bucket b) -> offs[b * G + g] relative to the bucket, row total
+//   offsets_finish_kernel  one workgroup: exclusive scan of the nb row totals -> where
+//                          each bucket starts in the packed array, and its size
+// A region's absolute write offset for bucket b is bucket_start[b] + offs[b * G + g].
+__global__ __launch_bounds__(1024) void offsets_rows_kernel(const uint32_t *hist, unsigned long long *offs, uint32_t G,
+                                                            unsigned long long *row_total) {
     __shared__ unsigned long long s_w[16];
     __shared__ unsigned long long s_base;
-    const uint32_t tid = threadIdx.x;
-    const uint64_t total = (uint64_t)nb * G;
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    for (uint64_t start = 0; start < total; start += 1024) {
-        const uint64_t i = start + tid;
-        const unsigned long long v = (i < total) ? hist[i] : 0;
+    for (uint32_t start = 0; start < G; start += 1024) {
+        const uint32_t i = start + tid;
+        const unsigned long long v = (i < G) ? hist[(size_t)b * G + i] : 0;
         const unsigned long long inc = wave_incl_scan(v);
         if ((tid & 63) == 63) s_w[tid >> 6] = inc;
         __syncthreads();
         unsigned long long woff = 0;
         for (uint32_t w = 0; w < (tid >> 6); ++w) woff += s_w[w];
         const unsigned long long base = s_base;
-        const unsigned long long excl = base + woff + inc - v;
-        if (i < total) {
-            offs[i] = excl;
-            if (i % G == 0) bucket_start[i / G] = excl;
-        }
+        if (i < G) offs[(size_t)b * G + i] = base + woff + inc - v;
         __syncthreads();
         if (tid == 1023) s_base = base + woff + inc;
         __syncthreads();
     }
-    // sizes: start[b+1] - start[b]
+    if (tid == 0) row_total[b] = s_base;
+}
+__global__ __launch_bounds__(1024) void offsets_finish_kernel(uint32_t nb, unsigned long long *bucket_start,
+                                                              unsigned long long *bucket_cnt) {
+    // on entry bucket_cnt[b] = row total (nb <= 1024)
+    __shared__ unsigned long long s_w[16];
+    const uint32_t tid = threadIdx.x;
+    const unsigned long long v = (tid < nb) ? bucket_cnt[tid] : 0;
+    const unsigned long long inc = wave_incl_scan(v);
+    if ((tid & 63) == 63) s_w[tid >> 6] = inc;
     __syncthreads();
-    const unsigned long long grand = s_base;
-    for (uint32_t b = tid; b < nb; b += 1024)
-        bucket_cnt[b] = ((b + 1 < nb) ? bucket_start[b + 1] : grand) - bucket_start[b];
+    unsigned long long woff = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) woff += s_w[w];
+    if (tid < nb) bucket_start[tid] = woff + inc - v;
 }
 
 // Level 0 of a sharded run: split this workgroup's key log by owner GPU (fan-out
@@ -305,13 +313,14 @@ __global__ __launch_bounds__(1024) void offsets_kernel(const uint32_t *hist, uns
 // run, so consecutive lanes write consecutive keys.
 __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *src, const unsigned long long *src_cnt,
                                                               uint64_t src_cap, uint32_t nregions, uint64_t *dst,
-                                                              const unsigned long long *offs, uint32_t nown,
+                                                              const unsigned long long *offs,
+                                                              const unsigned long long *offs_base, uint32_t nown,
                                                               uint32_t shift) {
     __shared__ unsigned long long s_cur[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
         lds_barrier();
-        if (tid < nown) s_cur[tid] = offs[(size_t)tid * nregions + r];
+        if (tid < nown) s_cur[tid] = offs_base[tid] + offs[(size_t)tid * nregions + r];
         lds_barrier();
         const uint64_t n = min((uint64_t)src_cnt[r], src_cap);
         const uint64_t *in = src + (uint64_t)r * src_cap;

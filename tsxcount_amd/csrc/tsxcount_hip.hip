@@ -28,7 +28,7 @@ static thread_local std::string g_last_error;
         }                                                                                \
     } while (0)
 
-static const int SCAN_WG_PER_CU = 4;  // scan_log_kernel workgroups per CU (LDS 22 KiB, 140 VGPRs)
+static const int SCAN_WG_PER_CU = 5;  // scan_log_kernel workgroups per CU (LDS 22 KiB, 140 VGPRs)
 static const size_t STAGE_PIECE_DEFAULT = (size_t)64 << 20;  // bytes of FASTQ per host piece
 
 struct tsx_hip_map {
@@ -457,14 +457,15 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         return bits;
     };
     auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 32); };
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs, pl.nb1,
-                       (uint32_t)pl.g, pl.c_bstart, pl.c_bcnt);
+    hipLaunchKernelGGL(offsets_rows_kernel, dim3(pl.nb1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs,
+                       (uint32_t)pl.g, pl.c_bcnt);
+    hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, pl.nb1, pl.c_bstart, pl.c_bcnt);
     {   // level 1: every region -> packed array ordered by the top b1 bits of the home slot
         const uint32_t bits = ring_bits(pl.nb1);
         hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st, m->p, src,
                            region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u, m->d_buf[1],
-                           (const unsigned long long *)pl.d_offs, (unsigned long long *)nullptr, (uint64_t)0, pl.nb1,
-                           (uint32_t)(p.l - pl.b1), bits);
+                           (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
+                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits);
         HIP_TRY(hipGetLastError());
     }
     const uint64_t *lists = m->d_buf[1];
@@ -476,7 +477,8 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.nb1 * pl.cpr2), dim3(PART_NT), part_lds(pl.nb2, bits), st, m->p,
                            (const uint64_t *)m->d_buf[1], (const unsigned long long *)pl.c_bstart,
                            (const unsigned long long *)pl.c_bcnt, (uint64_t)0, pl.nb1, pl.cpr2, m->d_buf[0],
-                           (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits);
+                           (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, pl.c_seg,
+                           pl.cap_sub, pl.nb2, (uint32_t)p.S, bits);
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
@@ -554,11 +556,13 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     if (shard_send) {
         // level 0: split every log region by owner into the caller's send buffer (exact offsets)
         if ((uint64_t)greg * pl.log_cap > shard_cap) return TSX_HIP_ERANGE;
-        hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs, nown,
-                           (uint32_t)greg, pl.c_bstart, pl.c_bcnt);
+        hipLaunchKernelGGL(offsets_rows_kernel, dim3(nown), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs,
+                           (uint32_t)greg, pl.c_bcnt);
+        hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, nown, pl.c_bstart, pl.c_bcnt);
         hipLaunchKernelGGL(split_owner_kernel, dim3(std::min(greg, m->cus * 8)), dim3(PART_NT), 0, st,
                            (const uint64_t *)m->d_buf[0], (const unsigned long long *)pl.c_log, pl.log_cap,
-                           (uint32_t)greg, shard_send, (const unsigned long long *)pl.d_offs, nown, (uint32_t)p.l);
+                           (uint32_t)greg, shard_send, (const unsigned long long *)pl.d_offs,
+                           (const unsigned long long *)pl.c_bstart, nown, (uint32_t)p.l);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(shard_counts, pl.c_bcnt, nown * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
     } else {
