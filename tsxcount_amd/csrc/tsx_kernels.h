@@ -1,7 +1,7 @@
 // tsx_kernels.h -- the HIP kernels of the counting path (gfx950, wave64).
 //
 //   line_count_kernel   FASTQ pass 1: non-empty line terminators per tile
-//   line_scan_kernel    FASTQ pass 2: exclusive scan -> line index at tile start
+//   line_*scan* kernels FASTQ pass 2: exclusive scan -> line index at tile start
 //   count_fastq_kernel  FASTQ pass 3: scan + 2-bit encode + hash + dedup + insert
 //   add_kmers_kernel    addKmer for a batch of encoded k-mers
 //   get_counts_kernel   getKmerCount(kmer) for a batch
@@ -91,29 +91,56 @@ __global__ __launch_bounds__(NT) void line_count_kernel(const uint8_t *buf, uint
     }
 }
 
-// Pass 2: one workgroup turns tile_cnt into the line index at each tile start
-// (in place, exclusive), starting from *carry (lines seen in earlier pieces)
-// and leaving the running total there.
-__global__ __launch_bounds__(1024) void line_scan_kernel(uint32_t *tile_cnt, uint64_t ntiles, uint32_t *carry) {
+// Pass 2: tile_cnt -> line index at each tile start (exclusive scan, in place), starting
+// from *carry (lines seen in earlier pieces) and leaving the running total there.
+// Three small launches: chunk sums, scan of the chunk sums, scan inside each chunk.
+constexpr int SCAN_CHUNK = 1024;
+__global__ __launch_bounds__(SCAN_CHUNK) void line_chunk_sum_kernel(const uint32_t *tile_cnt, uint64_t ntiles,
+                                                                    uint32_t *chunk_sum) {
+    __shared__ uint32_t s_w[SCAN_CHUNK / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    uint32_t v = (i < ntiles) ? tile_cnt[i] : 0;
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SCAN_CHUNK / 64; ++w) t += s_w[w];
+        chunk_sum[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void line_chunk_scan_kernel(uint32_t *chunk_sum, uint64_t nchunks, uint32_t *carry) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_base;
     if (threadIdx.x == 0) s_base = *carry;
     __syncthreads();
-    for (uint64_t start = 0; start < ntiles; start += 1024) {
+    for (uint64_t start = 0; start < nchunks; start += 1024) {
         const uint64_t i = start + threadIdx.x;
-        const uint32_t v = (i < ntiles) ? tile_cnt[i] : 0;
+        const uint32_t v = (i < nchunks) ? chunk_sum[i] : 0;
         const uint32_t inc = wave_incl_scan(v);
         if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
         __syncthreads();
         uint32_t woff = 0;
         for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_w[w];
         const uint32_t base = s_base;
-        if (i < ntiles) tile_cnt[i] = base + woff + inc - v;
+        if (i < nchunks) chunk_sum[i] = base + woff + inc - v;
         __syncthreads();
         if (threadIdx.x == 1023) s_base = base + woff + inc;
         __syncthreads();
     }
     if (threadIdx.x == 0) *carry = s_base;
+}
+__global__ __launch_bounds__(SCAN_CHUNK) void line_scan_kernel(uint32_t *tile_cnt, uint64_t ntiles,
+                                                               const uint32_t *chunk_base) {
+    __shared__ uint32_t s_w[SCAN_CHUNK / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    const uint32_t v = (i < ntiles) ? tile_cnt[i] : 0;
+    const uint32_t inc = wave_incl_scan(v);
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = chunk_base[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += s_w[w];
+    if (i < ntiles) tile_cnt[i] = woff + inc - v;
 }
 
 // Extract the k-mer that starts at byte position p of the tile from the packed

@@ -506,7 +506,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     if (ntiles > m->tile_cap) {
         if (m->d_tile) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(m->d_tile)); m->d_tile = nullptr; }
         m->tile_cap = ntiles + ntiles / 4 + 1024;
-        HIP_TRY(hipMalloc((void **)&m->d_tile, m->tile_cap * sizeof(uint32_t)));
+        // tile counts, then one partial sum per SCAN_CHUNK tiles
+        HIP_TRY(hipMalloc((void **)&m->d_tile, (m->tile_cap + m->tile_cap / SCAN_CHUNK + 16) * sizeof(uint32_t)));
     }
     hipEvent_t *ev = nullptr;
     if (m->timing) {
@@ -518,7 +519,15 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
     hipLaunchKernelGGL(line_count_kernel, dim3(g1), dim3(NT), 0, st, d_text, n, own_end, head_open, m->d_tile, ntiles);
-    hipLaunchKernelGGL(line_scan_kernel, dim3(1), dim3(1024), 0, st, m->d_tile, ntiles, m->d_carry);
+    {
+        const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        uint32_t *chunk = m->d_tile + m->tile_cap;
+        hipLaunchKernelGGL(line_chunk_sum_kernel, dim3((uint32_t)nchunks), dim3(SCAN_CHUNK), 0, st,
+                           (const uint32_t *)m->d_tile, ntiles, chunk);
+        hipLaunchKernelGGL(line_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, chunk, nchunks, m->d_carry);
+        hipLaunchKernelGGL(line_scan_kernel, dim3((uint32_t)nchunks), dim3(SCAN_CHUNK), 0, st, m->d_tile, ntiles,
+                           (const uint32_t *)chunk);
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     const size_t lut_bytes = m->lut.size() * 8;
     const int g3 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3);
