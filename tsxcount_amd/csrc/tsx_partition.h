@@ -384,26 +384,24 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
                                                               uint64_t list_cap, uint32_t pieces, uint32_t nseg,
                                                               int dbg) {
     extern __shared__ uint64_t s_seg[];  // 2^S slots
+    __shared__ uint32_t s_pn[8];         // sizes of the segment's sub-lists
     const uint32_t nslots = 1u << p.S;
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        // a segment's keys: one packed run (list_start) or up to 8 sub-lists of list_cap.
-        // e[c] = number of keys in sub-lists 0..c (wave-uniform, stays in scalar registers)
-        uint64_t e[8];
+        // a segment's keys: one packed run (list_start) or up to 8 sub-lists of list_cap
         uint64_t n = 0;
         const uint64_t *in0;
+        uint32_t npieces;
         if (list_start) {
             n = (uint64_t)list_cnt[seg];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) e[c] = n;
             in0 = lists + (uint64_t)list_start[seg];
+            npieces = 1;
+            if (tid == 0) s_pn[0] = (uint32_t)n;
         } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if ((uint32_t)c < pieces) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
-                e[c] = n;
-            }
+            for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
             in0 = lists + (uint64_t)seg * pieces * list_cap;
+            npieces = pieces;
+            if (tid < pieces) s_pn[tid] = (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + tid], list_cap);
         }
         if (n == 0) continue;
         uint64_t *slots = p.table + ((uint64_t)seg << p.S);
@@ -417,30 +415,32 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
                 *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
         }
         lds_barrier();
-        auto fetch = [&](uint64_t idx) -> uint64_t {  // idx-th key of the segment, 0 past the end
-            if (idx >= n) return 0;
-            uint64_t c = 0, before = 0;
-#pragma unroll
-            for (int t = 0; t < 7; ++t)
-                if (idx >= e[t]) { c = t + 1; before = e[t]; }
-            return in0[c * list_cap + (idx - before)];
-        };
         const uint64_t one = 1ULL << p.cshift;
-        // Every lane streams its own keys (tid, tid+nt, ...): one probe per loop round,
-        // and a lane that has placed its key moves straight on to its next one, so the
-        // wave stays full until the lists run dry instead of idling on its longest probe
-        // chain.  Three keys per lane are always in flight from HBM.
-        uint64_t r = tid;
-        uint64_t cur = fetch(r);
-        uint64_t f1 = fetch(r + nt);
-        uint64_t f2 = fetch(r + 2ULL * nt);
-        uint64_t f3 = fetch(r + 3ULL * nt);
-        bool live = (r < n) && !(dbg & 2);
+        // Every lane streams its own keys (the tid-th, tid+nt-th, ... of the segment): one
+        // probe per loop round, and a lane that has placed its key moves straight on to
+        // its next one, so the wave stays full until the lists run dry instead of idling
+        // on its longest probe chain.  BUILD_AHEAD keys per lane are in flight from HBM.
+        // The read cursor (piece, offset) advances by nt per fetch.
+        constexpr int BUILD_AHEAD = 7;
+        uint32_t pc = 0, poff = tid, pn = s_pn[0];
+        auto fetch_next = [&]() -> uint64_t {  // key at the cursor (0 past the end), then advance
+            while (pc < npieces && poff >= pn) { poff -= pn; ++pc; pn = (pc < npieces) ? s_pn[pc] : 0; }
+            const uint64_t v = (pc < npieces) ? in0[(uint64_t)pc * list_cap + poff] : 0ULL;
+            poff += nt;
+            return v;
+        };
+        uint64_t remaining = (tid < n) ? (n - tid + nt - 1) / nt : 0;  // keys this lane will insert
+        uint64_t cur = fetch_next();
+        uint64_t fifo[BUILD_AHEAD];
+#pragma unroll
+        for (int u = 0; u < BUILD_AHEAD; ++u) fifo[u] = fetch_next();
+        bool live = (remaining > 0) && !(dbg & 2);
         uint32_t i = 1;
+        uint32_t q0 = (uint32_t)(cur & p.seg_mask);
+        uint64_t e0 = ((cur >> p.lg) << p.R) & p.k0mask;  // split_key for WK = 1
         while (live) {
-            const uint32_t q0 = (uint32_t)(cur & p.seg_mask);
-            const uint64_t key0 = (((cur >> p.lg) << p.R) & p.k0mask) | i;  // split_key for WK = 1
             const uint32_t q = (q0 + ((i * (i + 1)) >> 1)) & (uint32_t)p.seg_mask;
+            const uint64_t key0 = e0 | i;
             const unsigned long long old =
                 atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
             bool placed = (old == 0ULL);
@@ -456,11 +456,14 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
                 placed = true;
             }
             if (placed) {
-                r += nt;
-                live = r < n;
-                cur = f1; f1 = f2; f2 = f3;
-                f3 = fetch(r + 3ULL * nt);
+                live = --remaining > 0;
+                cur = fifo[0];
+#pragma unroll
+                for (int u = 0; u + 1 < BUILD_AHEAD; ++u) fifo[u] = fifo[u + 1];
+                fifo[BUILD_AHEAD - 1] = fetch_next();
                 i = 1;
+                q0 = (uint32_t)(cur & p.seg_mask);
+                e0 = ((cur >> p.lg) << p.R) & p.k0mask;
             } else {
                 ++i;
             }
