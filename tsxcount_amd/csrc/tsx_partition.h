@@ -17,7 +17,7 @@
 namespace tsx {
 
 constexpr int PART_NT = 256;
-constexpr int PART_RPT = 4;      // keys per thread per batch
+constexpr int PART_RPT = 8;      // keys per thread per batch
 constexpr int PART_FLUSH = 8;    // records per burst (64 B)
 
 // One radix level.  Source = `nregions` regions of `src_cap` records each
