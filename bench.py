@@ -214,7 +214,8 @@ def main():
                                        else ", per-GPU tables merged over RCCL all-to-all") if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
                        "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL"},
-            "roofline": {"bound": "hbm", "kernel": "count_fastq_kernel<1>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "scan_log_kernel" if partitioned else "count_fastq_kernel<1>",
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
                          "line_pass_ms": scan_ms / pieces, "partition_build_ms": build_ms / pieces,

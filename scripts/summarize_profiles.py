@@ -46,8 +46,8 @@ for k, v in agg.items():
                               "TCC_EA0_ATOMIC_sum": v.get("TCC_EA0_ATOMIC_sum")}
         tot_r += rd
         tot_w += wr
-scan = part["kernels"].get("tsx::count_fastq_kernel<1>", {})
-part["kernel"] = "tsx::count_fastq_kernel<1>"
+scan = part["kernels"].get("tsx::scan_log_kernel", {})
+part["kernel"] = "tsx::scan_log_kernel"
 part["hbm_bytes_per_launch"] = scan.get("hbm_read_bytes", 0) + scan.get("hbm_write_bytes", 0)
 part["hbm_bytes_whole_path_per_step"] = tot_r + tot_w
 lc = agg.get("tsx::line_count_kernel", {})
