@@ -61,6 +61,7 @@ typedef struct tsx_hip_stats {
     uint64_t distinct;         /* occupied slots = getKmerCount() (TSXHashMap.h:645) */
     uint64_t overflow_used;    /* occupied secondary slots */
     uint64_t lock_timeouts;    /* multi-limb claim spins that gave up (must be 0) */
+    uint64_t fallback_inserts; /* keys the partitioned path inserted atomically because a list was full */
 } tsx_hip_stats;
 
 int tsx_hip_key_limbs(int k);

@@ -250,6 +250,30 @@ def test_device_entry_point_equals_host_entry_point(T):
     m.close()
 
 
+def test_device_entry_point_windows(T):
+    """Device texts are processed in windows (4 GiB in production); small windows put the
+    seams inside lines, inside k-mer windows and on newlines, for both insert paths."""
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, torch; import tsxcount_amd as T;"
+            "from tsxcount_amd import synth; text = synth.fastq(14, 0, 500);"
+            "buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).to('cuda:0');"
+            "m = T.TSXHashMapHIP(20, 0, 31); m.set_path(sys.argv[2]); torch.cuda.synchronize();"
+            "m.countFastqDevice(buf.data_ptr(), len(text)); m.sync(); k, c = m.getAllKmers();"
+            "o = np.lexsort(k.T[::-1]); np.save(sys.argv[1], np.concatenate([k[o].ravel(), c[o]]))" % ROOT)
+    from tsxcount_amd import synth
+    import tempfile
+    text = synth.fastq(14, 0, 500)
+    o, n = oracle_for(text, 31, 20, 4)
+    kmers, counts = o.dump()
+    b = np.lexsort(kmers.T[::-1])
+    expect = np.concatenate([kmers[b].ravel(), counts[b]])
+    for window, path in (("4096", "atomic"), ("100000", "partitioned"), ("65536", "atomic")):
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "r.npy")
+            env = dict(os.environ, TSX_HIP_DEV_WINDOW=window)
+            subprocess.run([sys.executable, "-c", code, f, path], check=True, env=env, timeout=300)
+            assert np.array_equal(np.load(f), expect), (window, path)
+
+
 def test_synth_kernel_matches_numpy_generator(T):
     import torch
     from tsxcount_amd import synth

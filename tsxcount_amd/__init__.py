@@ -39,7 +39,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("kmers_added", ctypes.c_uint64), ("insert_failures", ctypes.c_uint64),
                 ("overflow_carries", ctypes.c_uint64), ("overflow_failures", ctypes.c_uint64),
                 ("distinct", ctypes.c_uint64), ("overflow_used", ctypes.c_uint64),
-                ("lock_timeouts", ctypes.c_uint64)]
+                ("lock_timeouts", ctypes.c_uint64), ("fallback_inserts", ctypes.c_uint64)]
 
     def as_dict(self):
         return {f: int(getattr(self, f)) for f, _ in self._fields_}

@@ -29,6 +29,7 @@ enum StatIdx {
     ST_LOCKTO = 4,     // bounded lock spins that expired
     ST_SCRATCH = 5,    // reductions (distinct, ...)
     ST_SCRATCH2 = 6,
+    ST_FALLBACK = 7,   // keys the partitioned path handed to insert_key (a list or log region was full)
     ST_N = 8
 };
 

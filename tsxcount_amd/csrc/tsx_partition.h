@@ -173,7 +173,11 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
 
     auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
         if (at < lim) dst[at] = key;
-        else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }  // sub-list full: atomic path
+        else {  // sub-list full: atomic path
+            const uint64_t h[1] = {key};
+            atomicAdd(&p.stats[ST_FALLBACK], 1ULL);
+            insert_key<1>(p, h, 1);
+        }
     };
     auto flush = [&](bool all) {
         for (uint32_t b = tid; b < nb; b += PART_NT) {  // (A)

@@ -687,7 +687,7 @@ extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count
 // Device texts are processed in windows so that the partition scratch (about
 // 10 bytes per text byte) stays bounded; windows overlap by the k-1 byte halo
 // exactly like the host pieces.
-static const size_t DEV_WINDOW = (size_t)4 << 30;
+static const size_t DEV_WINDOW_DEFAULT = (size_t)4 << 30;
 
 extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream) {
     if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15)) return TSX_HIP_EINVAL;
@@ -696,6 +696,11 @@ extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, 
     HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
     const uint8_t *base = (const uint8_t *)dev_text;
     const size_t halo = (size_t)m->p.k - 1;
+    size_t DEV_WINDOW = DEV_WINDOW_DEFAULT;
+    if (const char *e = getenv("TSX_HIP_DEV_WINDOW")) {  // tests exercise the window seams
+        const long long v = atoll(e);
+        if (v >= 4096) DEV_WINDOW = ((size_t)v + 15) & ~(size_t)15;
+    }
     for (size_t off = 0; off < n || off == 0; off += DEV_WINDOW) {
         const size_t own = std::min(DEV_WINDOW, n - off);
         const size_t len = std::min(own + halo, n - off);
@@ -843,6 +848,7 @@ extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
     out->overflow_carries = st[ST_CARRY];
     out->overflow_failures = st[ST_SECFAIL];
     out->lock_timeouts = st[ST_LOCKTO];
+    out->fallback_inserts = st[ST_FALLBACK];
     out->distinct = st[ST_SCRATCH];
     out->overflow_used = st[ST_SCRATCH2];
     return TSX_HIP_OK;

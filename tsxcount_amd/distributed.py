@@ -21,6 +21,64 @@ def shard_reads(n_reads_total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
+A2A_CHUNK = 16 << 20  # elements (128 MiB of int64) per pair and round
+
+
+def exchange_rows(inp, in_sizes, out_sizes, group=None, chunk=A2A_CHUNK):
+    """All-to-all of int64 rows, robust against large messages.
+
+    `inp` is 1-D int64, grouped by destination rank (in_sizes[p] elements for rank p);
+    the result is grouped by source rank (out_sizes[p] elements from rank p).
+
+    Measured on this stack (ROCm 7.2 RCCL, torch 2.10): one all_to_all_single of
+    >= 1.2 GB delivers only half of the payload intact (scripts/a2a_test.py; 128 MiB is
+    fine, all_gather is fine at 6.4 GB).  So: the part a rank keeps never goes through
+    the collective, peers are served in rounds of at most `chunk` elements per pair,
+    and a per-pair checksum (sum modulo 2^64) travels separately and is verified.
+    """
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    gloo = dist.get_backend(group) == "gloo"
+    dev = inp.device
+    in_off = [0] * (world + 1)
+    out_off = [0] * (world + 1)
+    for p in range(world):
+        in_off[p + 1] = in_off[p] + in_sizes[p]
+        out_off[p + 1] = out_off[p] + out_sizes[p]
+    out = torch.empty((out_off[world],), dtype=inp.dtype, device=dev)
+    out[out_off[rank]:out_off[rank + 1]] = inp[in_off[rank]:in_off[rank + 1]]
+    peers = [p for p in range(world) if p != rank]
+    most = max([max(in_sizes[p], out_sizes[p]) for p in peers], default=0)
+    r = torch.tensor([(most + chunk - 1) // chunk], dtype=torch.int64, device="cpu" if gloo else dev)
+    if world > 1:
+        dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+    for t in range(int(r.item())):
+        ss = [0 if p == rank else max(0, min(chunk, in_sizes[p] - t * chunk)) for p in range(world)]
+        rs = [0 if p == rank else max(0, min(chunk, out_sizes[p] - t * chunk)) for p in range(world)]
+        send = torch.cat([inp[in_off[p] + t * chunk: in_off[p] + t * chunk + ss[p]] for p in range(world)])
+        recv = torch.empty((sum(rs),), dtype=inp.dtype, device="cpu" if gloo else dev)
+        dist.all_to_all_single(recv, send.cpu() if gloo else send, output_split_sizes=rs, input_split_sizes=ss,
+                               group=group)
+        at = 0
+        for p in range(world):
+            if rs[p]:
+                out[out_off[p] + t * chunk: out_off[p] + t * chunk + rs[p]] = recv[at:at + rs[p]].to(dev)
+                at += rs[p]
+    # integrity: checksums of what was meant for each peer vs what arrived from each peer
+    mine = torch.stack([inp[in_off[p]:in_off[p + 1]].sum() for p in range(world)]).to(torch.int64)
+    theirs = torch.empty_like(mine)
+    if gloo:
+        t_cpu = torch.empty((world,), dtype=torch.int64)
+        dist.all_to_all_single(t_cpu, mine.cpu(), group=group)
+        theirs = t_cpu.to(dev)
+    else:
+        dist.all_to_all_single(theirs, mine, group=group)
+    got = torch.stack([out[out_off[p]:out_off[p + 1]].sum() for p in range(world)]).to(torch.int64)
+    if not torch.equal(got, theirs):
+        raise RuntimeError("all-to-all payload corrupted in transit (checksum mismatch from ranks %s)"
+                           % [p for p in range(world) if int(got[p]) != int(theirs[p])])
+    return out
+
+
 def exchange_segments(kmers, counts, seg_counts, group=None):
     """All-to-all of owner-grouped table entries.
 
@@ -31,16 +89,20 @@ def exchange_segments(kmers, counts, seg_counts, group=None):
     """
     world = dist.get_world_size(group)
     wk = kmers.shape[1]
+    gloo = dist.get_backend(group) == "gloo"
     send_sizes = seg_counts.to(torch.int64).contiguous()
     recv_sizes = torch.empty_like(send_sizes)
-    dist.all_to_all_single(recv_sizes, send_sizes, group=group)
+    if gloo and send_sizes.is_cuda:
+        r_cpu = torch.empty((world,), dtype=torch.int64)
+        dist.all_to_all_single(r_cpu, send_sizes.cpu(), group=group)
+        recv_sizes = r_cpu
+    else:
+        dist.all_to_all_single(recv_sizes, send_sizes, group=group)
     ss = [int(x) for x in send_sizes.tolist()]
     rs = [int(x) for x in recv_sizes.tolist()]
     assert len(ss) == world and sum(ss) == kmers.shape[0]
-    recv_k = torch.empty((sum(rs), wk), dtype=kmers.dtype, device=kmers.device)
-    recv_c = torch.empty((sum(rs),), dtype=counts.dtype, device=counts.device)
-    dist.all_to_all_single(recv_k, kmers.contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
-    dist.all_to_all_single(recv_c, counts.contiguous(), output_split_sizes=rs, input_split_sizes=ss, group=group)
+    recv_k = exchange_rows(kmers.contiguous().view(-1), [x * wk for x in ss], [x * wk for x in rs], group).view(-1, wk)
+    recv_c = exchange_rows(counts.contiguous(), ss, rs, group)
     return recv_k, recv_c
 
 
@@ -58,12 +120,7 @@ def merge_tables(hmap, group=None):
     _check(hmap._lib.tsx_hip_partition_device(hmap.handle, world, ctypes.c_void_p(kmers.data_ptr()),
                                               ctypes.c_void_p(counts.data_ptr()), max(n, 1),
                                               ctypes.c_void_p(seg.data_ptr()), None))
-    if dist.get_backend(group) == "gloo":
-        # CPU collective (tests: several ranks sharing one GPU): stage through host memory
-        rk, rc = exchange_segments(kmers[:n].cpu(), counts[:n].cpu(), seg.cpu(), group)
-        recv_k, recv_c = rk.to(dev), rc.to(dev)
-    else:
-        recv_k, recv_c = exchange_segments(kmers[:n], counts[:n], seg, group)
+    recv_k, recv_c = exchange_segments(kmers[:n], counts[:n], seg, group)
     torch.cuda.synchronize(dev)
     hmap.clear()
     if recv_k.shape[0]:
@@ -127,9 +184,7 @@ class ShardedCounter:
         self._a2a(recv_sizes, self.counts)
         rs = [int(x) for x in recv_sizes.tolist()]
         n_recv = sum(rs)
-        if self.recv.numel() < n_recv:
-            self.recv = torch.empty((n_recv + n_recv // 8 + 1024,), dtype=torch.int64, device=self.dev)
-        self._a2a(self.recv[:n_recv], self.send[:sum(ss)], rs, ss)
+        self.recv = exchange_rows(self.send[:sum(ss)], ss, rs, self.group)
         # hot (key, count) lists: pad to the longest, gather everywhere, owners pick theirs
         nh = torch.tensor([min(int(self.hot_n.item()), self.HOT_CAP)], dtype=torch.int64,
                           device="cpu" if self.gloo else self.dev)
