@@ -166,14 +166,21 @@ class TSXHashMapHIP:
         self.k, self.l, self.wk, self.device = iK, iL, self.layout.key_limbs, device
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self._lib.tsx_hip_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.tsx_hip_destroy(h)
+            self._h = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter teardown: ctypes may already be gone
+            pass
 
     @property
     def handle(self):
+        if self._h is None:
+            raise TSXException(EINVAL, "map is closed")
         return self._h
 
     # --- reference surface -------------------------------------------------

@@ -73,9 +73,13 @@ def exchange_rows(inp, in_sizes, out_sizes, group=None, chunk=A2A_CHUNK):
     else:
         dist.all_to_all_single(theirs, mine, group=group)
     got = torch.stack([out[out_off[p]:out_off[p + 1]].sum() for p in range(world)]).to(torch.int64)
-    if not torch.equal(got, theirs):
-        raise RuntimeError("all-to-all payload corrupted in transit (checksum mismatch from ranks %s)"
-                           % [p for p in range(world) if int(got[p]) != int(theirs[p])])
+    bad = [p for p in range(world) if int(got[p]) != int(theirs[p])]
+    ok = torch.tensor([0 if bad else 1], dtype=torch.int64, device="cpu" if gloo else dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)  # every rank fails together, nobody hangs
+    if int(ok.item()) == 0:
+        raise RuntimeError("all-to-all payload corrupted in transit (rank %d: checksum mismatch from ranks %s)"
+                           % (rank, bad))
     return out
 
 
