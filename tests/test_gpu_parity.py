@@ -85,6 +85,36 @@ def test_cli_check_passes_on_golden(T, tmp_path):
     assert "Reference kmer count: 194697" in out
 
 
+def test_reference_binary_checks_hip_counts(T, tmp_path):
+    """The REAL reference (oracle/_ref/tsxCount_ref, built from /root/reference by
+    oracle/Makefile) counts the same FASTQ in CAS mode and --check's its table against a
+    .count file written FROM THE HIP TABLE: 'total errors0' and equal distinct counts
+    mean its getKmerCount agrees with ours for every k-mer.  threads=1, 2k+s = 64: the
+    configuration in which the reference's byte-wise CAS is exact."""
+    import re
+    from tsxcount_amd import synth
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "tsxCount_ref")
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference binary not built (oracle/Makefile needs /root/reference)")
+    k = 31
+    text = synth.fastq(77, 0, 40)
+    m = T.TSXHashMapHIP(18, 0, k)
+    m.countFastq(text)
+    kmers, counts = m.getAllKmers()
+    fq = tmp_path / "in.fastq"
+    fq.write_bytes(text)
+    with open(str(fq) + ".%d.count" % k, "w") as f:
+        for i in range(len(kmers)):
+            f.write("%s\t%d\n" % (T.decode(kmers[i], k), int(counts[i])))
+    p = subprocess.run([ref_bin, "--input=%s" % fq, "--k=%d" % k, "--l=18", "--s=2", "--mode=CAS", "--threads=1",
+                        "--check"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0
+    assert int(re.search(r"total errors(\d+)", out).group(1)) == 0
+    assert int(re.search(r"Added a total of (\d+) different kmers", out).group(1)) == len(kmers) == m.stats()["distinct"]
+    m.close()
+
+
 # --- oracle parity over k, table geometry and slot width ------------------------------
 
 @pytest.mark.parametrize("k,l,s,reads", [
