@@ -449,11 +449,11 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
 static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_t *src,
                                const unsigned long long *region_start, uint64_t src_cap, hipStream_t st) {
     const TableParams &p = m->p;
-    // ring depth: 7 keys may stay behind a flush, plus one batch's arrivals (mean = batch / nb)
+    // ring depth: PART_FLUSH-1 keys may stay behind a flush, plus one batch of arrivals (mean = batch / nb)
     auto ring_bits = [](uint32_t nb) {
         const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_RPT / nb);
         uint32_t bits = 4;
-        while ((1u << bits) < 8 + 2 * mean && bits < 6) ++bits;
+        while ((1u << bits) < PART_FLUSH + 2 * mean && bits < 6) ++bits;
         return bits;
     };
     auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 32); };
