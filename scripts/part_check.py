@@ -30,4 +30,6 @@ check(synth.fastq(9, 0, 2000), 31, 24)
 check(synth.fastq(9, 0, 20), 21, 15, 2)
 check(open('tests/golden/small_t7.1000.fastq','rb').read(), 14, 26, 4)
 check(synth.zipf_fastq(7, 3000, 150, 400, 31), 31, 18)
+check(synth.fastq(10, 0, 6000), 31, 31)   # 512 x 256 lists
+check(synth.fastq(11, 0, 3000), 27, 32)   # 512 x 512 lists
 print("PART OK")

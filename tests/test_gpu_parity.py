@@ -30,7 +30,7 @@ def oracle_for(text, k, l=20, s=4):
 
 
 def assert_same_as_oracle(T, text, k, l, s=0, path="auto", **kw):
-    o, n = oracle_for(text, k, min(max(l, 16), 2 * k - 1), 4)
+    o, n = oracle_for(text, k, min(max(l, 16), 24, 2 * k - 1), 4)  # the oracle's own table size is free
     m = T.TSXHashMapHIP(l, s, k, **kw)
     m.set_path(path)
     try:
@@ -156,15 +156,15 @@ def test_mapping_matches_oracle_and_inverts(T):
 
 @pytest.mark.parametrize("k,l,s,reads", [
     (31, 15, 0, 15), (31, 16, 0, 40), (31, 18, 0, 150), (31, 20, 4, 400), (31, 23, 0, 1500), (31, 24, 0, 2500),
-    (14, 18, 4, 100), (21, 17, 2, 60), (32, 19, 0, 400), (27, 22, 0, 1000)])
+    (14, 18, 4, 100), (21, 17, 2, 60), (32, 19, 0, 400), (27, 22, 0, 1000), (31, 31, 0, 2000), (27, 32, 0, 1500)])
 def test_partitioned_path_parity_with_oracle(T, k, l, s, reads):
-    """l = 15..22: one radix level; l >= 23: two levels.  Same counts as the oracle and
+    """l = 15..22: one radix level; l >= 23: two levels (l = 31, 32: 512 lists per level).  Same counts as the oracle and
     as the atomic path, also when the same text is counted twice into the table
     (second pass merges into segments that already hold data)."""
     from tsxcount_amd import synth
     text = synth.fastq(200 + k + l, 0, reads)
     assert_same_as_oracle(T, text, k, l, s, path="partitioned")
-    o, n = oracle_for(text, k, min(max(l, 16), 2 * k - 1), 4)
+    o, n = oracle_for(text, k, min(max(l, 16), 24, 2 * k - 1), 4)
     kmers, counts = o.dump()
     m = T.TSXHashMapHIP(l, s, k)
     m.set_path("partitioned")

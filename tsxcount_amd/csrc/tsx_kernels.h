@@ -181,11 +181,7 @@ __device__ __forceinline__ bool kmer_eq(const uint64_t (&a)[WK], const uint64_t 
 template <int WK>
 __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableParams p, const uint8_t *buf, uint64_t n,
                                                          uint64_t own_end, int head_open,
-                                                         const uint32_t *tile_line, uint64_t ntiles, int dbg,
-                                                         uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt,
-                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift,
-                                                         uint64_t *hot_keys, uint64_t *hot_cnts, uint64_t hot_cap,
-                                                         unsigned long long *hot_n) {
+                                                         const uint32_t *tile_line, uint64_t ntiles, int dbg) {
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
     __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
     __shared__ uint64_t s_le[TILE / 64];
@@ -193,39 +189,16 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     __shared__ uint32_t s_wsum[NT / 64];
     __shared__ uint32_t s_dpos[DSLOTS];
     __shared__ uint32_t s_dcnt[DSLOTS];
-    constexpr int HOT_N = 8;
-    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hist[256];  // level-1 bucket sizes of this workgroup's log region (nb1 <= 256)
     extern __shared__ uint64_t s_lut[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int lut_words = p.groups * (1 << p.g) * WK;
     for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
     for (int i = tid; i < DSLOTS; i += NT) { s_dpos[i] = 0; s_dcnt[i] = 0; }
-    if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
-    for (int i = tid; i < 256; i += NT) s_hist[i] = 0;
     if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
     if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
     unsigned long long added = 0;
     const uint32_t k = (uint32_t)p.k;
-    // partitioned path (WK == 1): single occurrences go to this workgroup's own
-    // region of the key log instead of the table; no global atomic is involved
-    uint64_t *my_log = log ? log + (uint64_t)blockIdx.x * log_cap : nullptr;
-    uint32_t log_fill = 0;  // identical in every thread
-    // Sharded table: keys that bypass the log (hot keys, a full log region) may belong to
-    // another GPU, so they go to a small (key, count) list that is exchanged instead of
-    // into the local table.
-    auto side_insert = [&](const uint64_t (&hkey)[WK], uint64_t d) {
-        if (hot_keys) {
-            const unsigned long long at = atomicAdd(hot_n, 1ULL);
-            if (at < hot_cap) { hot_keys[at] = hkey[0]; hot_cnts[at] = d; }
-            else atomicAdd(&p.stats[ST_FAIL], (unsigned long long)d);
-        } else {
-            insert_key<WK>(p, hkey, d);
-        }
-    };
-
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
         lds_barrier();  // previous tile's LDS fully consumed
@@ -312,93 +285,25 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                 }
             }
             lds_barrier();
-            // Phase B.  Totals are final now.  Three destinations:
-            //   d == 1 and a key log   -> this workgroup's log region (partitioned path)
-            //   d  > 1 and a key log   -> the wave's hot cache (flushed once at kernel end)
-            //   otherwise              -> the table, one CAS (+ add) per key
-            uint32_t wave_emit = 0;
+            // Phase B.  Totals are final now: the claimant of each dedup slot issues ONE global
+            // insert carrying the slot's total (one CAS for a new key, CAS + add otherwise).
 #pragma unroll
             for (int j = 0; j < PER_THREAD; ++j) {
-                uint64_t d = 0;
-                if (slot_of[j] != -1) {
-                    d = direct_cnt[j];
-                    if (slot_of[j] >= 0) {
-                        d = s_dcnt[slot_of[j]];
-                        s_dcnt[slot_of[j]] = 0;
-                        s_dpos[slot_of[j]] = 0;
-                    }
+                if (slot_of[j] == -1) continue;
+                uint64_t d = direct_cnt[j];
+                if (slot_of[j] >= 0) {
+                    d = s_dcnt[slot_of[j]];
+                    s_dcnt[slot_of[j]] = 0;
+                    s_dpos[slot_of[j]] = 0;
                 }
-                direct_cnt[j] = 0;  // from here on: 1 = this lane writes hk[j] to the log
-                if (WK == 1 && my_log) {
-                    if (d == 1) direct_cnt[j] = 1;
-                    // d > 1: hot keys (homopolymer tails, tandem repeats).  The few lanes of the
-                    // wave that carry one take turns folding it into the wave's 8 cached keys.
-                    unsigned long long hot = __ballot(d > 1);
-                    while (hot) {
-                        const int src = __builtin_ctzll(hot);
-                        hot &= hot - 1;
-                        if (lane == src && !(dbg & 1)) {
-                            uint64_t *hkey = s_hot_key + (tid >> 6) * HOT_N;
-                            uint32_t *hcnt = s_hot_cnt + (tid >> 6) * HOT_N;
-                            int at = -1;
-                            for (int q = 0; q < HOT_N; ++q)
-                                if (hcnt[q] && hkey[q] == hk[j][0]) { at = q; break; }
-                            if (at < 0)
-                                for (int q = 0; q < HOT_N; ++q)
-                                    if (!hcnt[q]) { at = q; hkey[q] = hk[j][0]; break; }
-                            if (at >= 0 && (uint64_t)hcnt[at] + d < 0xFFFFFFF0ULL) hcnt[at] += (uint32_t)d;
-                            else side_insert(hk[j], d);
-                        }
-                    }
-                    wave_emit += (uint32_t)__builtin_popcountll(__ballot(d == 1));
-                } else if (d != 0) {
-                    if (!(dbg & 1)) insert_key<WK>(p, hk[j], d);
-                    else if (d == 0xFFFFFFFFFFULL) p.stats[ST_SCRATCH] = hk[j][0];  // keep the hash alive
-                }
-            }
-            if (WK == 1 && my_log) {
-                // one contiguous run of the log region per wave and j: consecutive lanes
-                // write consecutive keys (full 64-B sectors), offsets are scalar arithmetic
-                if (lane == 0) s_wsum[tid >> 6] = wave_emit;
-                lds_barrier();
-                uint32_t off = log_fill, total = 0;
-                for (int w = 0; w < NT / 64; ++w) {
-                    if (w < (tid >> 6)) off += s_wsum[w];
-                    total += s_wsum[w];
-                }
-#pragma unroll
-                for (int j = 0; j < PER_THREAD; ++j) {
-                    const unsigned long long mk = __ballot(direct_cnt[j] == 1);
-                    if (direct_cnt[j] == 1) {
-                        const uint32_t at = off + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
-                        if (at < log_cap) {
-                            my_log[at] = hk[j][0];
-                            if (hist) atomicAdd(&s_hist[(uint32_t)(hk[j][0] >> hist_shift) & (hist_nb - 1)], 1u);
-                        } else if (!(dbg & 1)) {
-                            side_insert(hk[j], 1);  // region full: atomic path
-                        }
-                    }
-                    off += (uint32_t)__builtin_popcountll(mk);
-                }
-                log_fill += total;
+                if (!(dbg & 1)) insert_key<WK>(p, hk[j], d);
+                else if (d == 0xFFFFFFFFFFULL) p.stats[ST_SCRATCH] = hk[j][0];  // keep the hash alive in ablation runs
             }
             lds_barrier();
         }
     }
-    if (WK == 1 && my_log) {  // flush the hot caches: a handful of atomics per workgroup
-        lds_barrier();
-        if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) {
-            const uint64_t h1[WK] = {s_hot_key[tid]};
-            side_insert(h1, s_hot_cnt[tid]);
-        }
-    }
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
     if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
-    if (log_cnt && tid == 0) log_cnt[blockIdx.x] = min((uint64_t)log_fill, log_cap);
-    if (hist) {
-        lds_barrier();
-        for (uint32_t b = tid; b < hist_nb; b += NT) hist[(size_t)b * gridDim.x + blockIdx.x] = s_hist[b];
-    }
 }
 
 // Pass 3 of the partitioned path (k <= 32): scan -> 2-bit encode -> hash -> key log.
@@ -426,13 +331,13 @@ __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const ui
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hist[(NT / 64) * 256];
+    __shared__ uint32_t s_hist[(NT / 64) * 512];  // level-1 fan-out <= 512
     extern __shared__ uint64_t s_lut[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lut_words = p.groups * (1 << p.g);
     for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
-    for (int i = tid; i < (NT / 64) * 256; i += NT) s_hist[i] = 0;
+    for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
     if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
     if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
     if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
@@ -441,7 +346,7 @@ __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const ui
     const uint32_t need = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
     uint64_t *my_log = log + (uint64_t)region * log_cap;
-    uint32_t *my_hist = s_hist + wave * 256;
+    uint32_t *my_hist = s_hist + wave * 512;
     uint32_t fill = 0;  // wave-uniform
 
     auto side_insert = [&](uint64_t hkey, uint64_t d) {

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(PART_NT) void partition_kernel(TableParams p, const
 // 128-B line; 64-B bursts cost 0.8 ms more in level 1) and where; (B) 8 consecutive
 // lanes per list copy them, with the LDS reads of all lists an octet serves issued
 // before the first store.
-constexpr int PART_ITER = 8;  // lists per octet: nb <= PART_ITER * PART_NT / 8 = 256
+constexpr int PART_ITER = 8;  // lists an octet serves per pass of the flush (256 lists per pass)
 __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
@@ -194,33 +194,35 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         }
         lds_barrier();
         const uint32_t oct = tid >> 3, ol = tid & 7;  // (B)
-        unsigned long long meta[PART_ITER], lim[PART_ITER];
-        uint64_t k0[PART_ITER], k1[PART_ITER];
+        for (uint32_t g0 = 0; g0 < nb; g0 += PART_ITER * (PART_NT / 8)) {
+            unsigned long long meta[PART_ITER], lim[PART_ITER];
+            uint64_t k0[PART_ITER], k1[PART_ITER];
 #pragma unroll
-        for (int u = 0; u < PART_ITER; ++u) {
-            const uint32_t b = oct + u * (PART_NT / 8);
-            meta[u] = (b < nb) ? s_meta[b] : 0ULL;
-            lim[u] = (b < nb) ? s_lim[b] : 0ULL;
-        }
+            for (int u = 0; u < PART_ITER; ++u) {
+                const uint32_t b = g0 + oct + u * (PART_NT / 8);
+                meta[u] = (b < nb) ? s_meta[b] : 0ULL;
+                lim[u] = (b < nb) ? s_lim[b] : 0ULL;
+            }
 #pragma unroll
-        for (int u = 0; u < PART_ITER; ++u) {
-            const uint32_t b = oct + u * (PART_NT / 8);
-            const uint32_t nout = (uint32_t)(meta[u] & 0xFF), hd = (uint32_t)(meta[u] >> 8) & 0xFF;
-            const uint64_t *ring = s_stage + ((size_t)b << capbits);
-            k0[u] = (ol < nout) ? ring[(hd + ol) & cmask] : 0;
-            k1[u] = (ol + 8 < nout) ? ring[(hd + ol + 8) & cmask] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < PART_ITER; ++u) {
-            const uint32_t nout = (uint32_t)(meta[u] & 0xFF);
-            const unsigned long long at = meta[u] >> 16;
-            if (ol < nout) put(k0[u], at + ol, lim[u]);
-            if (ol + 8 < nout) put(k1[u], at + ol + 8, lim[u]);
-            if (nout > 16) {  // only rings deeper than 16 or the final flush get here
-                const uint32_t b = oct + u * (PART_NT / 8);
-                const uint32_t hd = (uint32_t)(meta[u] >> 8) & 0xFF;
+            for (int u = 0; u < PART_ITER; ++u) {
+                const uint32_t b = g0 + oct + u * (PART_NT / 8);
+                const uint32_t nout = (uint32_t)(meta[u] & 0xFF), hd = (uint32_t)(meta[u] >> 8) & 0xFF;
                 const uint64_t *ring = s_stage + ((size_t)b << capbits);
-                for (uint32_t q = ol + 16; q < nout; q += 8) put(ring[(hd + q) & cmask], at + q, lim[u]);
+                k0[u] = (ol < nout) ? ring[(hd + ol) & cmask] : 0;
+                k1[u] = (ol + 8 < nout) ? ring[(hd + ol + 8) & cmask] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < PART_ITER; ++u) {
+                const uint32_t nout = (uint32_t)(meta[u] & 0xFF);
+                const unsigned long long at = meta[u] >> 16;
+                if (ol < nout) put(k0[u], at + ol, lim[u]);
+                if (ol + 8 < nout) put(k1[u], at + ol + 8, lim[u]);
+                if (nout > 16) {  // only rings deeper than 16 or the final flush get here
+                    const uint32_t b = g0 + oct + u * (PART_NT / 8);
+                    const uint32_t hd = (uint32_t)(meta[u] >> 8) & 0xFF;
+                    const uint64_t *ring = s_stage + ((size_t)b << capbits);
+                    for (uint32_t q = ol + 16; q < nout; q += 8) put(ring[(hd + q) & cmask], at + q, lim[u]);
+                }
             }
         }
     };
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *sr
 __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uint64_t n, uint64_t region_len,
                                                        uint32_t G, uint32_t nb, uint32_t shift, uint32_t *hist,
                                                        unsigned long long *region_start, unsigned long long *region_cnt) {
-    __shared__ uint32_t s_h[256];
+    __shared__ uint32_t s_h[512];
     const uint32_t tid = threadIdx.x;
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
         lds_barrier();

@@ -377,7 +377,7 @@ struct PartPlan {
 static bool can_partition(const tsx_hip_map *m) {
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
-    return p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 16;  // two levels of <= 256 lists
+    return p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 18;  // two levels of <= 512 lists
 }
 
 template <typename T>
@@ -399,8 +399,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     const int nsegbits = p.l - p.S;
     pl.g = g;
     pl.nseg = 1u << nsegbits;
-    // level-1 fan-out is capped at 256 (the scan kernel keeps that histogram in LDS)
-    pl.b1 = std::min(8, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
+    // fan-out per level is capped at 512 (histogram of the scan kernel and ring staging live in LDS)
+    pl.b1 = std::min(9, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
     pl.b2 = nsegbits - pl.b1;
     pl.nb1 = 1u << pl.b1; pl.nb2 = 1u << pl.b2;
     pl.hist_nb = hist_nb_override ? hist_nb_override : pl.nb1;
@@ -539,10 +539,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const bool use_part = shard_send || (can_partition(m) && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes)));
     if (!use_part) {
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
-                                          own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg,
-                                          (uint64_t *)nullptr, (uint64_t)0, (unsigned long long *)nullptr,
-                                          (uint32_t *)nullptr, 0u, 0u, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                                          (uint64_t)0, (unsigned long long *)nullptr));
+                                          own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
         HIP_TRY(hipGetLastError());
         if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
         return TSX_HIP_OK;
