@@ -137,18 +137,57 @@ def test_other_hash_seeds_give_the_same_counts(T):
         assert_same_as_oracle(T, text, 31, 18, 0, hash_seed=seed)
 
 
-def test_mapping_matches_oracle_and_inverts(T):
+def test_mapping_is_bijective_linear_and_mixes_all_bits(T):
+    """IBijectiveFunction contract (IBijectiveFunction.h:26-27): apply/inv_apply are inverse,
+    GF(2)-linear.  Unlike the reference's unit upper triangular matrix (the oracle's family:
+    output bit p ignores input bits above p) the product's L*U matrix lets the top key bits
+    reach the slot index, so k-mers that share a prefix do not share a home slot."""
     from oracle.oracle import Oracle
     for k in (14, 31, 63, 127):
-        o = Oracle(k, 12, 4, seed=5)
         m = T.TSXHashMapHIP(12, 0, k, hash_seed=5)
-        assert np.array_equal(m.hash_rows(), o.hash_rows())
+        n = 2 * k
         rng = np.random.default_rng(k)
+        top = np.uint64((1 << (n % 64 or 64)) - 1)
+
+        def rnd():
+            x = rng.integers(0, 2 ** 63, size=m.wk, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=m.wk, dtype=np.uint64)
+            x[-1] &= top
+            return x
         for _ in range(20):
-            x = rng.integers(0, 2 ** 63, size=m.wk, dtype=np.uint64)
-            x[-1] &= np.uint64((1 << ((2 * k) % 64 or 64)) - 1)
-            assert np.array_equal(m.hash_apply(x), o.hash_apply(x))
+            x, y = rnd(), rnd()
             assert np.array_equal(m.hash_invert(m.hash_apply(x)), x)
+            assert np.array_equal(m.hash_apply(m.hash_invert(x)), x)
+            assert np.array_equal(m.hash_apply(x ^ y), m.hash_apply(x) ^ m.hash_apply(y))
+        # flipping the LAST base of the k-mer (top two key bits) moves the home slot
+        moved = 0
+        for _ in range(64):
+            x = rnd()
+            y = x.copy()
+            y[(n - 1) >> 6] ^= np.uint64(1) << np.uint64((n - 1) & 63)
+            moved += int((int(m.hash_apply(x)[0]) ^ int(m.hash_apply(y)[0])) & 0xFFF != 0)
+        assert moved == 64  # one fixed non-zero column of the matrix: all or nothing
+        # the reference's family, for contrast: the low bits never see the top bit
+        o = Oracle(k, 12, 4, seed=5)
+        x = rnd(); y = x.copy(); y[(n - 1) >> 6] ^= np.uint64(1) << np.uint64((n - 1) & 63)
+        assert (int(o.hash_apply(x)[0]) ^ int(o.hash_apply(y)[0])) & 0xFFF == 0
+        m.close()
+
+
+def test_prefix_skew_does_not_exhaust_reprobes(T):
+    """AT-rich reads: thousands of k-mers share their first 12-15 bases.  With the reference's
+    triangular matrix they would share one home slot and one probe chain; at load 0.5 the
+    8-bit reprobe field must still be enough, on both insert paths."""
+    rng = np.random.default_rng(1)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    codes = rng.choice(4, size=(8000, 300), p=[0.4, 0.1, 0.1, 0.4])
+    text = b"".join(b"@r%d\n" % r + lut[codes[r]].tobytes() + b"\n+\n" + b"I" * 300 + b"\n" for r in range(8000))
+    for path in ("atomic", "partitioned"):
+        m = T.TSXHashMapHIP(22, 0, 31)
+        m.set_path(path)
+        m.countFastq(text)
+        st = m.stats()
+        assert st["insert_failures"] == 0 and st["kmers_added"] == 8000 * 270
+        assert 0.45 < st["distinct"] / (1 << 22) < 0.55
         m.close()
 
 

@@ -109,10 +109,19 @@ extern "C" int tsx_hip_decode(const uint64_t *limbs, int k, char *out) {
 }
 
 // ---- bijective GF(2) mapping ------------------------------------------------
-// Same family as BijectiveKMapping::getRandomMatrix (BijectiveKMapping.h:284-303):
-// unit upper triangular, random above the diagonal.  Row i carries bit
-// (n-1-j) = M[i][j] (matrixToRows, :227-256) and yields output bit n-1-i
-// (applyto, :202-225).  Seeded splitmix64 replaces srand(time(NULL)).
+// The reference draws a random UNIT UPPER TRIANGULAR matrix over GF(2)
+// (BijectiveKMapping::getRandomMatrix, BijectiveKMapping.h:284-303; row i carries bit
+// n-1-j = M[i][j] (matrixToRows, :227-256) and yields output bit n-1-i (applyto,
+// :202-225)).  With that family output bit p depends only on input bits <= p, so the
+// slot index (the low l bits) is a function of the first l/2 bases alone: all k-mers
+// that share a 15-base prefix share one home slot AND one probe sequence.  The
+// reference survives that with up to 2^l reprobes; an 8-bit reprobe field does not
+// (AT-rich reads at load 0.48 already exhausted 255 probes, scripts/skew_check.py).
+// So the matrix here is M = L * U with U drawn exactly like the reference's matrix and
+// L a unit LOWER triangular matrix from the same generator: still bijective and
+// GF(2)-linear (same IBijectiveFunction contract, same LUT evaluation), but every
+// key bit reaches the slot index.  Counts do not depend on the matrix.  Seeded
+// splitmix64 replaces srand(time(NULL)).
 static uint64_t splitmix_next(uint64_t &st) {
     uint64_t z = (st += 0x9E3779B97F4A7C15ULL);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -127,27 +136,40 @@ static void make_mapping(tsx_hip_map *m) {
     m->rows.assign((size_t)n * wk, 0);
     m->irows.assign((size_t)n * wk, 0);
     uint64_t st = m->seed, word = 0; int have = 0;
+    auto draw = [&]() { if (!have) { word = splitmix_next(st); have = 64; } const int b = (int)(word & 1); word >>= 1; --have; return b; };
+    // U: unit upper triangular in (row i, column j) terms, as bit masks over input bit positions
+    std::vector<uint64_t> U((size_t)n * wk, 0), Lm((size_t)n * wk, 0);
     for (int i = 0; i < n; ++i) {
-        uint64_t *row = &m->rows[(size_t)i * wk];
-        rset(row, n - 1 - i);
-        for (int j = i + 1; j < n; ++j) {
-            if (!have) { word = splitmix_next(st); have = 64; }
-            if (word & 1) rset(row, n - 1 - j);
-            word >>= 1; --have;
-        }
+        rset(&U[(size_t)i * wk], n - 1 - i);
+        for (int j = i + 1; j < n; ++j) if (draw()) rset(&U[(size_t)i * wk], n - 1 - j);
     }
-    // y_p = x_p ^ sum_{q<p} a[p][q] x_q  =>  x_p = y_p ^ sum_{q<p} a[p][q] x_q(y)
-    std::vector<uint64_t> xform((size_t)n * wk, 0);
-    for (int pbit = 0; pbit < n; ++pbit) {
-        const uint64_t *row = &m->rows[(size_t)(n - 1 - pbit) * wk];
-        uint64_t *acc = &xform[(size_t)pbit * wk];
-        rset(acc, pbit);
-        for (int q = 0; q < pbit; ++q)
-            if (rbit(row, q))
-                for (int t = 0; t < wk; ++t) acc[t] ^= xform[(size_t)q * wk + t];
+    // L: unit lower triangular; Lm[i] = mask over ROW indices j <= i of U that row i of M sums
+    for (int i = 0; i < n; ++i) {
+        rset(&Lm[(size_t)i * wk], i);
+        for (int j = 0; j < i; ++j) if (draw()) rset(&Lm[(size_t)i * wk], j);
     }
-    for (int pbit = 0; pbit < n; ++pbit)
-        memcpy(&m->irows[(size_t)(n - 1 - pbit) * wk], &xform[(size_t)pbit * wk], (size_t)wk * 8);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j)
+            if (rbit(&Lm[(size_t)i * wk], j))
+                for (int t = 0; t < wk; ++t) m->rows[(size_t)i * wk + t] ^= U[(size_t)j * wk + t];
+    // Inverse by Gauss-Jordan on [A | I], A[r][c] = coefficient of input bit c in output bit r
+    // (output bit r is produced by rows[n-1-r]).
+    std::vector<uint64_t> A((size_t)n * wk), I((size_t)n * wk, 0);
+    for (int r = 0; r < n; ++r) {
+        memcpy(&A[(size_t)r * wk], &m->rows[(size_t)(n - 1 - r) * wk], (size_t)wk * 8);
+        rset(&I[(size_t)r * wk], r);
+    }
+    for (int c = 0; c < n; ++c) {
+        int piv = -1;
+        for (int r = c; r < n; ++r) if (rbit(&A[(size_t)r * wk], c)) { piv = r; break; }
+        // L and U are unit triangular, so M is always invertible and a pivot exists
+        if (piv != c) for (int t = 0; t < wk; ++t) { std::swap(A[(size_t)piv * wk + t], A[(size_t)c * wk + t]); std::swap(I[(size_t)piv * wk + t], I[(size_t)c * wk + t]); }
+        for (int r = 0; r < n; ++r)
+            if (r != c && rbit(&A[(size_t)r * wk], c))
+                for (int t = 0; t < wk; ++t) { A[(size_t)r * wk + t] ^= A[(size_t)c * wk + t]; I[(size_t)r * wk + t] ^= I[(size_t)c * wk + t]; }
+    }
+    // input bit c = XOR of the output bits in I[c]; irows[i] yields original bit n-1-i
+    for (int c = 0; c < n; ++c) memcpy(&m->irows[(size_t)(n - 1 - c) * wk], &I[(size_t)c * wk], (size_t)wk * 8);
 }
 
 static void apply_rows(const tsx_hip_map *m, const std::vector<uint64_t> &rows, const uint64_t *x, uint64_t *out) {
