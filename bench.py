@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo only to rehearse N > 1 on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group, sharded table, collectives) even at world size 1: "
+                         "the only way to push the RCCL leg through its API on a 1-GPU box")
     args = ap.parse_args()
 
     import torch
@@ -99,8 +102,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29671")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
@@ -121,7 +126,7 @@ def main():
     # N > 1: ONE table sharded by slot range over the GPUs (2^(l + log2 N) slots in all, so the
     # load factor per GPU is the same at every N: weak scaling).  Keys travel to their owner
     # through one RCCL all-to-all before they are built; see tsxcount_amd/distributed.py.
-    sharded = world > 1 and (world & (world - 1)) == 0 and args.k <= 32 and args.merge == "shard"
+    sharded = dist_on and (world & (world - 1)) == 0 and args.k <= 32 and args.merge == "shard"
     bits = world.bit_length() - 1 if sharded else 0
     m = T.TSXHashMapHIP(args.l, 0, args.k, device=local_rank, shard_bits=bits, shard_index=rank if sharded else 0)
     m.set_path(args.path)
@@ -133,7 +138,7 @@ def main():
             sc.step(text.data_ptr(), nbytes)
         else:
             m.countFastqDevice(text.data_ptr(), nbytes)
-            if world > 1:
+            if dist_on:
                 TD.merge_tables(m)  # per-GPU tables merged afterwards (any N, any k)
             else:
                 m.sync()
@@ -141,21 +146,21 @@ def main():
     for _ in range(args.warmup):
         step()
     m.set_timing(True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     scan_ms, count_ms, build_ms, launches = m.get_timing()
     m.set_timing(False)
 
     # max over ranks
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -169,7 +174,7 @@ def main():
     check_ok = (st["insert_failures"] == 0 and st["overflow_failures"] == 0 and st["lock_timeouts"] == 0)
     if world == 1 or sharded:
         check_ok = check_ok and st["kmers_added"] == kmers_rank  # every k-mer of this rank's reads was scanned
-    if world > 1:
+    if dist_on:
         # every distinct k-mer ends up on exactly one rank; their number is the same whichever way the
         # reads were spread, and (almost) every non-polyA k-mer of this generator is unique
         dsum = torch.tensor([st["distinct"]], dtype=torch.int64, device=red)
@@ -229,7 +234,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     m.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -187,10 +187,15 @@ __device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK],
         if (old == 0ULL) {
             p.seg_dirty[pos >> p.S] = 1;  // idempotent plain store
             if (W > 1) {
-                for (int t = 1; t < W; ++t) atomicExch(e + t, (unsigned long long)hi[t - 1]);
-                // the limb stores must have landed before the slot is unlocked
+                // Publish the remaining limbs and drop the lock with write-through
+                // (agent-scope) stores instead of atomics: nobody else touches a locked
+                // slot (adders wait for the lock to clear), so the unlocked value of limb 0
+                // is known, and 3 atomics per new key become 1 atomic + W stores.  The
+                // limb stores must have landed before the unlock store is issued.
+                for (int t = 1; t < W; ++t)
+                    __hip_atomic_store(e + t, (unsigned long long)hi[t - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                atomicAnd(e, ~(unsigned long long)p.lock_bit);
+                __hip_atomic_store(e, (unsigned long long)(key0 | dlow), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             carry = d >> p.C; carry_pos = pos;
             state = 1;

@@ -552,25 +552,41 @@ __device__ __forceinline__ int owner_of(const uint64_t *x, int wk, int nranks) {
 
 // mode 0: count occupied slots per owner into seg[0..nranks)
 // mode 1: write k-mer + count at seg_cursor[owner]++ (cursors preset to segment starts)
+// One atomic per (wave, owner present in the wave): the lanes that share an owner are found
+// with ballots and take consecutive places behind the leader's atomicAdd.
 template <int WK>
 __global__ __launch_bounds__(NT) void dump_kernel(TableParams p, int nranks, int mode, uint64_t *kmers_out,
                                                   uint64_t *counts_out, uint64_t cap,
                                                   unsigned long long *seg) {
     const uint64_t slots = p.slot_mask + 1;
-    for (uint64_t pos = (uint64_t)blockIdx.x * NT + threadIdx.x; pos < slots; pos += (uint64_t)gridDim.x * NT) {
-        if (p.table[pos * (uint64_t)p.W] == 0) continue;
-        uint64_t x[WK], c;
-        slot_to_kmer<WK>(p, pos, x, c);
-        const int own = (nranks > 1) ? owner_of(x, WK, nranks) : 0;
-        if (mode == 0) {
-            atomicAdd(&seg[own], 1ULL);
-        } else {
-            const unsigned long long at = atomicAdd(&seg[own], 1ULL);
-            if (at < cap) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = (1ULL << lane) - 1ULL;
+    // wave-uniform trip count: every lane of a wave runs the same iterations
+    for (uint64_t base = (uint64_t)blockIdx.x * NT + (threadIdx.x & ~63u); base < slots; base += (uint64_t)gridDim.x * NT) {
+        const uint64_t pos = base + lane;
+        const bool occ = pos < slots && p.table[pos * (uint64_t)p.W] != 0;
+        uint64_t x[WK], c = 0;
+        int own = 0;
+        if (occ) {
+            slot_to_kmer<WK>(p, pos, x, c);
+            own = (nranks > 1) ? owner_of(x, WK, nranks) : 0;
+        }
+        uint64_t todo = __ballot(occ);
+        unsigned long long at = 0;
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const int o = __shfl(own, lead, 64);
+            const uint64_t grp = __ballot(occ && own == o);
+            unsigned long long b = 0;
+            if (lane == lead) b = atomicAdd(&seg[o], (unsigned long long)__popcll(grp));
+            b = __shfl(b, lead, 64);
+            if (occ && own == o) at = b + (unsigned long long)__popcll(grp & lt);
+            todo &= ~grp;
+        }
+        if (mode == 1 && occ && at < cap) {
 #pragma unroll
-                for (int t = 0; t < WK; ++t) kmers_out[at * WK + t] = x[t];
-                counts_out[at] = c;
-            }
+            for (int t = 0; t < WK; ++t) kmers_out[at * WK + t] = x[t];
+            counts_out[at] = c;
         }
     }
 }
