@@ -40,6 +40,7 @@ struct TableParams {
     unsigned long long *stats;  // ST_N device counters
     const uint64_t *lut;        // hash LUT   [groups][1<<g][WK]
     const uint64_t *ilut;       // inverse    [groups][1<<g][WK]
+    const uint64_t *roll;       // one-limb keys: sliding-window update table [64] (scan_log_kernel), else null
     uint64_t slot_mask;         // 2^l - 1
     uint64_t seg_mask;          // 2^S - 1: probing never leaves the 2^S-slot segment of its home slot
     uint8_t *seg_dirty;         // one byte per segment: 1 once the segment holds anything

@@ -306,15 +306,38 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
 }
 
+// Rare ways out of scan_log_kernel (log region full, hot cache full, end-of-kernel hot cache
+// drain): kept out of line and fed from the kernel-argument segment so that the table
+// parameters insert_key() needs do not occupy scalar registers inside the strip loop.
+__device__ __attribute__((noinline)) void scan_side_insert(const TableParams *pk, uint64_t hkey, uint64_t d,
+                                                           uint64_t *hot_keys, uint64_t *hot_cnts, uint64_t hot_cap,
+                                                           unsigned long long *hot_n) {
+    if (hot_keys) {  // sharded table: the key may belong to another GPU
+        const unsigned long long at = atomicAdd(hot_n, 1ULL);
+        if (at < hot_cap) { hot_keys[at] = hkey; hot_cnts[at] = d; }
+        else atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
+    } else {
+        const uint64_t h1[1] = {hkey};
+        insert_key<1>(*pk, h1, d);
+    }
+}
+
 // Pass 3 of the partitioned path (k <= 32): scan -> 2-bit encode -> hash -> key log.
 // Same tile front end as count_fastq_kernel; what differs is what happens to a k-mer:
+//   * every LANE walks a strip of 16 consecutive start positions.  For one-limb keys the
+//     mapping is x -> c*x in GF(2^2k) (make_mapping), so the hash of the next window follows
+//     from the current one with ONE 64-entry table lookup,
+//         h' = (h >> 2) ^ roll[(h & 3) | out_base << 2 | in_base << 4],
+//     instead of eight LUT lookups per k-mer; only the first window of a strip is hashed in
+//     full.  Validity of the 16 windows (no newline inside, sequence line of a 4-line
+//     record, inside this piece) is one bit mask per strip, built with shifts;
 //   * nothing is inserted and nothing is deduplicated per workgroup -- duplicates are
 //     summed where they meet anyway, in the LDS segment build;
-//   * every WAVE owns a region of the key log, so a run of keys is appended with one
-//     ballot and scalar arithmetic: no atomics, no workgroup barrier inside the
-//     position loop (two barriers per 4 KiB tile in all);
-//   * equal neighbours are still run-length merged across the wave; a run longer than
-//     one (homopolymer tails) goes to the wave's 8-entry hot cache with its length;
+//   * every WAVE owns a region of the key log, so keys are appended with one ballot and
+//     scalar arithmetic: no atomics, no workgroup barrier inside the strip loop (two
+//     barriers per 4 KiB tile in all);
+//   * equal consecutive k-mers (homopolymer runs) are counted in the lane, merged across
+//     the wave and folded into the wave's 8-entry hot cache with their total;
 //   * the level-1 histogram of each region is kept in LDS (exact offsets downstream).
 // Regions and histogram columns are indexed by blockIdx.x * 4 + wave.
 __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const uint8_t *buf, uint64_t n,
@@ -332,33 +355,32 @@ __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const ui
     __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hist[(NT / 64) * 512];  // level-1 fan-out <= 512
+    __shared__ uint64_t s_roll[64];
     extern __shared__ uint64_t s_lut[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lut_words = p.groups * (1 << p.g);
     for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
     for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
+    if (tid < 64) s_roll[tid] = p.roll[tid];
     if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
     if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
     if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
     unsigned long long added = 0;
     const uint32_t k = (uint32_t)p.k;
-    const uint32_t need = (k >= 32) ? 0xFFFFFFFFu : ((1u << k) - 1u);
     const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
     uint64_t *my_log = log + (uint64_t)region * log_cap;
     uint32_t *my_hist = s_hist + wave * 512;
     uint32_t fill = 0;  // wave-uniform
+    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
+    // windows that may start at all: inside the text and inside this piece
+    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
 
+    // TableParams is the first kernel argument: the slow path reads it from the argument segment
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     auto side_insert = [&](uint64_t hkey, uint64_t d) {
         if (dbg & 1) return;
-        if (hot_keys) {  // sharded table: the key may belong to another GPU
-            const unsigned long long at = atomicAdd(hot_n, 1ULL);
-            if (at < hot_cap) { hot_keys[at] = hkey; hot_cnts[at] = d; }
-            else atomicAdd(&p.stats[ST_FAIL], (unsigned long long)d);
-        } else {
-            const uint64_t h1[1] = {hkey};
-            insert_key<1>(p, h1, d);
-        }
+        scan_side_insert(pk, hkey, d, hot_keys, hot_cnts, hot_cap, hot_n);
     };
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -388,64 +410,121 @@ __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const ui
         }
         lds_barrier();
 
+        // ---- this lane's strip: start positions s .. s+15 of the tile -------------------
+        const uint32_t s0 = (uint32_t)tid * 16;
+        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
         const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
-#pragma unroll 4
-        for (int it = 0; it < TILE / NT; ++it) {
-            const uint32_t pp = (uint32_t)(it * NT + tid);
-            const uint64_t gpos = base + pp;
-            // line index of this byte: group base + line ends before it in the group
-            const uint32_t grp = pp >> 4;
-            const uint32_t le_before = reinterpret_cast<const uint16_t *>(s_le)[grp] & ((1u << (pp & 15)) - 1u);
-            const uint32_t line = (uint32_t)s_lb[grp] + __popc(le_before);
-            // no newline inside [pp, pp+k), k <= 32: one 32-bit funnel shift of the newline mask
-            const uint32_t w = pp >> 5, o = pp & 31;
-            const uint32_t win = __funnelshift_r(nl32[w], nl32[w + 1], o);
-            const bool valid = ((line & 3u) == 1u) && ((win & need) == 0u) && (gpos + k <= n) && (gpos < own_end);
-            // header, '+' and quality lines are half of a FASTQ text: skip waves without a k-mer start
-            if (__ballot(valid) == 0ULL) continue;
-            uint64_t x[1];
-            extract_kmer<1>(s_codes, pp, p.top_mask, x);
-            // run-length merge across the wave: lanes hold consecutive positions
-            const uint64_t xp = __shfl_up((unsigned long long)x[0], 1, 64);
-            const bool prev_valid = __shfl_up((int)valid, 1, 64) != 0;
-            const bool leader = valid && (lane == 0 || !prev_valid || x[0] != xp);
-            const unsigned long long bnd = __ballot(leader || !valid);
-            const unsigned long long above = (lane == 63) ? 0ULL : (bnd >> (lane + 1));
-            const uint32_t runlen = (above ? (uint32_t)__builtin_ctzll(above) : (uint32_t)(63 - lane)) + 1u;
-            added += valid ? 1ULL : 0ULL;
-            uint64_t h[1] = {0};
-            if (leader) hash_apply<1>(p, (const uint64_t *)s_lut, x, h);
-            // runs longer than one: fold into the wave's hot cache, one lane at a time
-            unsigned long long hot = __ballot(leader && runlen > 1);
-            while (hot) {
-                const int src = __builtin_ctzll(hot);
-                hot &= hot - 1;
+        // newline flags of bytes [s, s+64)
+        uint64_t m;
+        {
+            const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
+            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2];
+            m = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
+        }
+        // bad_j = a newline in [s+j, s+j+k): OR of m >> t for t < k, by doubling
+        uint64_t r = m;
+        uint32_t span = 1;
+        while (span * 2 <= k) { r |= r >> span; span *= 2; }
+        if (span < k) r |= r >> (k - span);
+        // line index of position j = lb + (line ends before j): two prefix-parity passes give it mod 4
+        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
+        const uint32_t lb = s_lb[tid];
+        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
+        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
+        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
+        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
+        const uint64_t g0 = base + s0;
+        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
+        const uint32_t vm = ~(uint32_t)r & b0 & ~b1 & ((1u << jmax) - 1u);   // line & 3 == 1, no newline, in range
+        added += (unsigned long long)__popc(vm);
+        // header, '+' and quality lines are half of a FASTQ text: skip waves without a k-mer start
+        if (__ballot(vm != 0u) == 0ULL) continue;
+
+        uint64_t h = 0;
+        if (vm) {
+            uint64_t x[1], hh[1];
+            extract_kmer<1>(s_codes, s0, p.top_mask, x);
+            hash_apply<1>(p, (const uint64_t *)s_lut, x, hh);
+            h = hh[0];
+        }
+        // bases leaving (s+j) and entering (s+j+k) when the window moves from j to j+1
+        const uint32_t cw0 = codes32[tid];
+        uint32_t inc;
+        {
+            const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
+            const uint32_t w0 = codes32[tid + ws], w1 = (ws < 2u) ? codes32[tid + ws + 1] : 0u;
+            inc = __funnelshift_r(w0, w1, sh);
+        }
+        // Pass A: the 16 hashes of the strip, by rolling.  The lane also tracks the run of equal
+        // k-mers (homopolymer) that is still open when the strip ends: reads end in such runs,
+        // and a run covers whole strips.  Its length goes to the wave's hot cache below; equal
+        // neighbours anywhere else in the strip are simply logged one by one.
+        uint64_t hs[16];
+        uint32_t runlen = 0;
+        uint64_t runkey = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            hs[j] = h;
+            const bool valid = (vm >> j) & 1u;
+            const bool eq = (j > 0) && valid && ((vm >> (j > 0 ? j - 1 : 0)) & 1u) && (h == runkey) && runlen;
+            if (eq) runlen += 1u;
+            else if (valid) { runlen = 1u; runkey = h; }
+            if (j < 15) {
+                const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
+                                     (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
+                h = (h >> 2) ^ s_roll[idx];
+            }
+        }
+        // the open run: positions [lv - runlen + 1, lv], lv = last valid position of the strip
+        uint32_t single = vm;
+        {
+            const bool hot = vm && runlen > 1u;
+            if (hot) {
+                const uint32_t lv = 31u - (uint32_t)__clz(vm);
+                single &= ~(((1u << runlen) - 1u) << (lv + 1u - runlen));
+            }
+            unsigned long long pend = __ballot(hot);
+            while (pend) {   // merge equal keys across the wave, then one hot-cache update per key
+                const int src = __builtin_ctzll(pend);
+                const uint64_t key = __shfl((unsigned long long)runkey, src, 64);
+                const bool mine = hot && runkey == key;
+                pend &= ~__ballot(mine);
+                uint32_t tot = mine ? runlen : 0u;
+                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
                 if (lane == src) {
                     uint64_t *hkey = s_hot_key + wave * HOT_N;
                     uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
                     int at = -1;
                     for (int q = 0; q < HOT_N; ++q)
-                        if (hcnt[q] && hkey[q] == h[0]) { at = q; break; }
+                        if (hcnt[q] && hkey[q] == key) { at = q; break; }
                     if (at < 0)
                         for (int q = 0; q < HOT_N; ++q)
-                            if (!hcnt[q]) { at = q; hkey[q] = h[0]; break; }
-                    if (at >= 0 && (uint64_t)hcnt[at] + runlen < 0xFFFFFFF0ULL) hcnt[at] += runlen;
-                    else side_insert(h[0], runlen);
+                            if (!hcnt[q]) { at = q; hkey[q] = key; break; }
+                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                    else side_insert(key, tot);
                 }
             }
-            // single occurrences: one contiguous run of this wave's log region
-            const bool emit = leader && runlen == 1;
-            const unsigned long long mk = __ballot(emit);
-            if (emit) {
-                const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
-                if (at < log_cap) {
-                    my_log[at] = h[0];
-                    atomicAdd(&my_hist[(uint32_t)(h[0] >> hist_shift) & (hist_nb - 1)], 1u);
-                } else {
-                    side_insert(h[0], 1);  // region full: atomic path (or the exchanged list)
+        }
+        // Pass B: everything else goes to this wave's log region, one contiguous run per strip position
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool em = (single >> j) & 1u;
+            const unsigned long long mk = __ballot(em);
+            if (mk) {
+                if (em) {
+                    const uint64_t key = hs[j];
+                    const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
+                    if (at < cap32) {
+                        my_log[at] = key;
+                        const uint32_t hb = (hist_shift < 32u) ? __funnelshift_r((uint32_t)key, (uint32_t)(key >> 32), hist_shift)
+                                                               : ((uint32_t)(key >> 32) >> (hist_shift - 32u));
+                        atomicAdd(&my_hist[hb & (hist_nb - 1)], 1u);
+                    } else {
+                        side_insert(key, 1);  // region full: atomic path (or the exchanged list)
+                    }
                 }
+                fill += (uint32_t)__builtin_popcountll(mk);
             }
-            fill += (uint32_t)__builtin_popcountll(mk);
         }
     }
     lds_barrier();
@@ -453,7 +532,7 @@ __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const ui
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
     if (lane == 0) {
         if (added) atomicAdd(&p.stats[ST_KMERS], added);
-        log_cnt[region] = min((uint64_t)fill, log_cap);
+        log_cnt[region] = min(fill, cap32);
     }
     for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
 }

@@ -447,56 +447,69 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
         }
         lds_barrier();
         const uint64_t one = 1ULL << p.cshift;
-        // Every lane streams its own keys (the tid-th, tid+nt-th, ... of the segment): one
-        // probe per loop round, and a lane that has placed its key moves straight on to
-        // its next one, so the wave stays full until the lists run dry instead of idling
-        // on its longest probe chain.  BUILD_AHEAD keys per lane are in flight from HBM.
-        // The read cursor (piece, offset) advances by nt per fetch.
-        constexpr int BUILD_AHEAD = 7;
-        uint32_t pc = 0, poff = tid, pn = s_pn[0];
-        auto fetch_next = [&]() -> uint64_t {  // key at the cursor (0 past the end), then advance
-            while (pc < npieces && poff >= pn) { poff -= pn; ++pc; pn = (pc < npieces) ? s_pn[pc] : 0; }
-            const uint64_t v = (pc < npieces) ? in0[(uint64_t)pc * list_cap + poff] : 0ULL;
-            poff += nt;
+        // Every lane streams its own keys: one probe per loop round, and a lane that has
+        // placed its key moves straight on to its next one, so the wave stays full until
+        // the lists run dry instead of idling on its longest probe chain.  The loop is
+        // VALU-issue bound (measured: same time with 10 or 16 waves per CU), so it is kept
+        // short: the probe position advances by addition (q_i = q_{i-1} + i), the slot
+        // image of the key is built once per key, and the read cursor is a plain pointer --
+        // with several sub-lists the workgroup splits into one thread group per sub-list.
+        // BUILD_AHEAD keys per lane are in flight from HBM.
+        constexpr int BUILD_AHEAD = 4;
+        uint32_t grp = 0, gl = tid, gstride = nt;
+        if (npieces > 1) {
+            gstride = nt / npieces;
+            grp = tid / gstride;
+            gl = tid - grp * gstride;
+        }
+        const uint32_t mine = (grp < npieces) ? s_pn[grp] : 0u;
+        const uint64_t *ptr = in0 + (uint64_t)grp * list_cap + gl;
+        uint32_t left = (gl < mine) ? (mine - gl + gstride - 1) / gstride : 0;   // keys this lane inserts
+        uint32_t ahead = left;                                                    // keys not fetched yet
+        auto fetch_next = [&]() -> uint64_t {
+            const uint64_t v = ahead ? *ptr : 0ULL;
+            ahead -= ahead ? 1u : 0u;
+            ptr += gstride;
             return v;
         };
-        uint64_t remaining = (tid < n) ? (n - tid + nt - 1) / nt : 0;  // keys this lane will insert
         uint64_t cur = fetch_next();
         uint64_t fifo[BUILD_AHEAD];
 #pragma unroll
         for (int u = 0; u < BUILD_AHEAD; ++u) fifo[u] = fetch_next();
-        bool live = (remaining > 0) && !(dbg & 2);
+        bool live = (left > 0) && !(dbg & 2);
+        const uint32_t smask = (uint32_t)p.seg_mask;
+        const uint64_t k0mask = p.k0mask;
+        const uint32_t maxr = p.max_reprobes;
         uint32_t i = 1;
-        uint32_t q0 = (uint32_t)(cur & p.seg_mask);
-        uint64_t e0 = ((cur >> p.lg) << p.R) & p.k0mask;  // split_key for WK = 1
+        uint32_t q = ((uint32_t)cur + 1u) & smask;                        // q_1 = q_0 + 1
+        uint64_t e0 = ((cur >> p.lg) << p.R) & k0mask;                    // split_key for WK = 1
         while (live) {
-            const uint32_t q = (q0 + ((i * (i + 1)) >> 1)) & (uint32_t)p.seg_mask;
             const uint64_t key0 = e0 | i;
             const unsigned long long old =
                 atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
             bool placed = (old == 0ULL);
-            if (!placed && (old & p.k0mask) == key0) {
+            if (!placed && (old & k0mask) == key0) {
                 const unsigned long long prev =
                     atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[q]), (unsigned long long)one);
                 const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
                 if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
                 placed = true;
             }
-            if (!placed && i + 1 > p.max_reprobes) {
+            if (!placed && i >= maxr) {
                 atomicAdd(&p.stats[ST_FAIL], 1ULL);
                 placed = true;
             }
+            ++i;
+            q = (q + i) & smask;
             if (placed) {
-                live = --remaining > 0;
+                live = --left > 0;
                 cur = fifo[0];
 #pragma unroll
                 for (int u = 0; u + 1 < BUILD_AHEAD; ++u) fifo[u] = fifo[u + 1];
                 fifo[BUILD_AHEAD - 1] = fetch_next();
                 i = 1;
-                q0 = (uint32_t)(cur & p.seg_mask);
-                e0 = ((cur >> p.lg) << p.R) & p.k0mask;
-            } else {
-                ++i;
+                q = ((uint32_t)cur + 1u) & smask;
+                e0 = ((cur >> p.lg) << p.R) & k0mask;
             }
         }
         lds_barrier();

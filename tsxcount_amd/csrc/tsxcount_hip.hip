@@ -41,7 +41,8 @@ struct tsx_hip_map {
     // bijective mapping, host copy: rows[i] yields output bit n-1-i
     std::vector<uint64_t> rows, irows;   // n x wk
     std::vector<uint64_t> lut, ilut;     // [groups][1<<g][wk]
-    uint64_t *d_lut = nullptr, *d_ilut = nullptr;
+    uint64_t *d_lut = nullptr, *d_ilut = nullptr, *d_roll = nullptr;
+    uint64_t roll[64] = {0};             // one-limb keys: sliding-window hash update table
     // FASTQ scratch
     uint32_t *d_tile = nullptr; uint64_t tile_cap = 0;
     uint32_t *d_carry = nullptr;
@@ -131,12 +132,67 @@ static uint64_t splitmix_next(uint64_t &st) {
 static inline int rbit(const uint64_t *r, int i) { return (int)((r[i >> 6] >> (i & 63)) & 1); }
 static inline void rset(uint64_t *r, int i) { r[i >> 6] |= 1ULL << (i & 63); }
 
-static void make_mapping(tsx_hip_map *m) {
+// Irreducible polynomials over GF(2) of degree 2, 4, ..., 64 (low terms; the leading term is
+// implied): trinomials where one exists, else pentanomials.  Found with Rabin's test; a wrong
+// entry would make the one-limb mapping singular, which make_mapping() reports.
+static const uint64_t GF_POLY_LOW[33] = {0, 0x3ULL, 0x3ULL, 0x3ULL, 0x87ULL, 0x9ULL, 0x9ULL, 0x21ULL, 0x47ULL, 0x9ULL, 0x9ULL,
+    0x3ULL, 0x87ULL, 0x47ULL, 0x3ULL, 0x3ULL, 0x813ULL, 0x81ULL, 0x201ULL, 0x87ULL, 0x20BULL, 0x81ULL, 0x21ULL, 0x3ULL,
+    0x823ULL, 0x207ULL, 0x9ULL, 0x201ULL, 0x8403ULL, 0x80001ULL, 0x3ULL, 0x20000001ULL, 0x807ULL};
+
+static inline uint64_t gf_mulz(uint64_t a, uint64_t plow, int n) {  // a * z in GF(2^n)
+    const uint64_t top = (a >> (n - 1)) & 1ULL;
+    a <<= 1;
+    if (n < 64) a &= (1ULL << n) - 1ULL;
+    return top ? (a ^ plow) : a;
+}
+static inline uint64_t gf_mul(uint64_t a, uint64_t b, uint64_t plow, int n) {
+    uint64_t r = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((b >> i) & 1ULL) r ^= a;
+        a = gf_mulz(a, plow, n);
+    }
+    return r;
+}
+
+// The bijective k-mer mapping (IBijectiveFunction / BijectiveKMapping in the reference: a random
+// invertible GF(2) matrix).  Multi-limb keys: M = L * U, random unit triangular factors.
+// One-limb keys (k <= 32): M = multiplication by a random element c of GF(2^2k), a universal
+// family whose matrix is dense like a random one -- and because the k-mer window slides by one
+// base (x' = (x >> 2) | b << (2k-2), i.e. x' = (x - low2) / z^2 + b z^(2k-2) as polynomials),
+//     c*x' = (c*x + c*low2) * z^-2 + c*b*z^(2k-2),
+// the scan kernel gets the hash of the next window from the current one with one lookup in the
+// 64-entry table roll[(h & 3) | out << 2 | in << 4] built here.
+static int make_mapping(tsx_hip_map *m) {
     const int n = m->p.n, wk = m->p.wk;
     m->rows.assign((size_t)n * wk, 0);
     m->irows.assign((size_t)n * wk, 0);
     uint64_t st = m->seed, word = 0; int have = 0;
     auto draw = [&]() { if (!have) { word = splitmix_next(st); have = 64; } const int b = (int)(word & 1); word >>= 1; --have; return b; };
+    if (wk == 1) {
+        const uint64_t plow = GF_POLY_LOW[n / 2], mask = (n < 64) ? ((1ULL << n) - 1ULL) : ~0ULL;
+        uint64_t c = 0;
+        while (c == 0 || c == 1) c = splitmix_next(st) & mask;       // 0 is not invertible, 1 is the identity
+        // column j of M is c * z^j; rows[i] yields output bit n-1-i
+        uint64_t col = c;
+        for (int j = 0; j < n; ++j) {
+            for (int r = 0; r < n; ++r)
+                if ((col >> r) & 1ULL) rset(&m->rows[(size_t)(n - 1 - r)], j);
+            col = gf_mulz(col, plow, n);
+        }
+        const uint64_t zinv = (plow >> 1) | (1ULL << (n - 1));       // z * zinv = 1 (P has constant term 1)
+        const uint64_t zinv2 = gf_mul(zinv, zinv, plow, n);
+        uint64_t A[4], C[4], E[4];
+        for (int v = 0; v < 4; ++v) {
+            A[v] = gf_mul(c, (uint64_t)v, plow, n);
+            C[v] = A[v];
+            for (int t = 0; t < n - 2; ++t) C[v] = gf_mulz(C[v], plow, n);
+            E[v] = ((v & 1) ? zinv2 : 0ULL) ^ ((v & 2) ? zinv : 0ULL);
+        }
+        for (int idx = 0; idx < 64; ++idx) {
+            const int hb = idx & 3, out = (idx >> 2) & 3, in = (idx >> 4) & 3;
+            m->roll[idx] = (A[out] >> 2) ^ E[(hb ^ (int)(A[out] & 3ULL)) & 3] ^ C[in];
+        }
+    } else {
     // U: unit upper triangular in (row i, column j) terms, as bit masks over input bit positions
     std::vector<uint64_t> U((size_t)n * wk, 0), Lm((size_t)n * wk, 0);
     for (int i = 0; i < n; ++i) {
@@ -152,6 +208,7 @@ static void make_mapping(tsx_hip_map *m) {
         for (int j = 0; j <= i; ++j)
             if (rbit(&Lm[(size_t)i * wk], j))
                 for (int t = 0; t < wk; ++t) m->rows[(size_t)i * wk + t] ^= U[(size_t)j * wk + t];
+    }
     // Inverse by Gauss-Jordan on [A | I], A[r][c] = coefficient of input bit c in output bit r
     // (output bit r is produced by rows[n-1-r]).
     std::vector<uint64_t> A((size_t)n * wk), I((size_t)n * wk, 0);
@@ -162,7 +219,7 @@ static void make_mapping(tsx_hip_map *m) {
     for (int c = 0; c < n; ++c) {
         int piv = -1;
         for (int r = c; r < n; ++r) if (rbit(&A[(size_t)r * wk], c)) { piv = r; break; }
-        // L and U are unit triangular, so M is always invertible and a pivot exists
+        if (piv < 0) return TSX_HIP_EINVAL;  // singular: cannot happen for L*U or for c != 0 with P irreducible
         if (piv != c) for (int t = 0; t < wk; ++t) { std::swap(A[(size_t)piv * wk + t], A[(size_t)c * wk + t]); std::swap(I[(size_t)piv * wk + t], I[(size_t)c * wk + t]); }
         for (int r = 0; r < n; ++r)
             if (r != c && rbit(&A[(size_t)r * wk], c))
@@ -170,6 +227,7 @@ static void make_mapping(tsx_hip_map *m) {
     }
     // input bit c = XOR of the output bits in I[c]; irows[i] yields original bit n-1-i
     for (int c = 0; c < n; ++c) memcpy(&m->irows[(size_t)(n - 1 - c) * wk], &I[(size_t)c * wk], (size_t)wk * 8);
+    return TSX_HIP_OK;
 }
 
 static void apply_rows(const tsx_hip_map *m, const std::vector<uint64_t> &rows, const uint64_t *x, uint64_t *out) {
@@ -229,6 +287,7 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l, in
     p.lock_bit = lock ? (1ULL << p.K0) : 0ULL;
     p.slot_mask = (1ULL << l) - 1ULL;
     p.S = std::min(l, 14);           // 2^14 one-limb slots = 128 KiB: one segment fits a CU's LDS
+    if (const char *e = getenv("TSX_HIP_SEG_BITS")) p.S = std::min(l, std::min(14, std::max(8, atoi(e))));
     p.seg_mask = (1ULL << p.S) - 1ULL;
     const uint64_t maxr = (1ULL << p.R) - 1ULL;
     p.max_reprobes = (uint32_t)std::min<uint64_t>(maxr, p.slot_mask);
@@ -301,14 +360,20 @@ extern "C" int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storage
     HIP_TRY_C(hipMalloc((void **)&p.seg_dirty, (size_t)(m->lay.slots >> p.S)));
     HIP_TRY_C(hipMalloc((void **)&m->d_carry, 64));
     HIP_TRY_C(hipMalloc((void **)&m->d_seg, 64 * sizeof(unsigned long long)));
-    make_mapping(m);
+    rc = make_mapping(m);
+    if (rc != TSX_HIP_OK) return fail(rc);
     make_lut(m, m->rows, m->lut);
     make_lut(m, m->irows, m->ilut);
     HIP_TRY_C(hipMalloc((void **)&m->d_lut, m->lut.size() * 8));
     HIP_TRY_C(hipMalloc((void **)&m->d_ilut, m->ilut.size() * 8));
     HIP_TRY_C(hipMemcpy(m->d_lut, m->lut.data(), m->lut.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY_C(hipMemcpy(m->d_ilut, m->ilut.data(), m->ilut.size() * 8, hipMemcpyHostToDevice));
-    p.lut = m->d_lut; p.ilut = m->d_ilut;
+    p.lut = m->d_lut; p.ilut = m->d_ilut; p.roll = nullptr;
+    if (p.wk == 1) {
+        HIP_TRY_C(hipMalloc((void **)&m->d_roll, sizeof(m->roll)));
+        HIP_TRY_C(hipMemcpy(m->d_roll, m->roll, sizeof(m->roll), hipMemcpyHostToDevice));
+        p.roll = m->d_roll;
+    }
     rc = tsx_hip_clear(m);
     if (rc != TSX_HIP_OK) return fail(rc);
     *out = m;
@@ -321,7 +386,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
-    (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut);
+    (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
     (void)hipFree(m->d_tile); (void)hipFree(m->d_carry); (void)hipFree(m->d_seg);
     (void)hipFree(m->p.seg_dirty); (void)hipFree(m->d_buf[0]); (void)hipFree(m->d_buf[1]); (void)hipFree(m->d_cnt);
     for (int i = 0; i < 2; ++i) {
@@ -506,8 +571,10 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
     if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
-        const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 4);
-        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(1024), (size_t)8 << p.S, st, m->p, lists, lists_start,
+        const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 16);
+        int bnt = 1024;
+        if (const char *e = getenv("TSX_HIP_BUILD_NT")) bnt = std::min(1024, std::max(64, atoi(e) & ~63));
+        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), (size_t)8 << p.S, st, m->p, lists, lists_start,
                            lists_cnt, lists_cap, pieces, pl.nseg, m->dbg);
         HIP_TRY(hipGetLastError());
     }
