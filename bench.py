@@ -156,7 +156,9 @@ def main():
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    scan_ms, count_ms, build_ms, launches = m.get_timing()
+    stage, launches = m.get_stage_timing()
+    scan_ms, count_ms = stage["line"], stage["scan"]
+    build_ms = stage["level1"] + stage["level2"] + stage["build"]
     m.set_timing(False)
 
     # max over ranks
@@ -190,10 +192,23 @@ def main():
         # the partitioned path reads the text and writes one 8-byte key per logged k-mer) and
         # for the whole device path of a step.
         pieces = max(launches, 1)
-        kern_ms = count_ms / pieces
         partitioned = build_ms / pieces > 0.5
         keys_logged = st["distinct"] if partitioned else 0
-        kern_bytes = nbytes + (8.0 * keys_logged if partitioned else 16.0 * kmers_rank)
+        # algorithmic bytes of each stage of one launch: the scan kernel reads the
+        # text and writes one 8-byte key per logged k-mer (atomic path: reads the text, reads + writes one
+        # slot per k-mer); a radix level reads and writes every key once; the build reads every key once
+        # and writes every slot of the table once.
+        table_bytes = 8.0 * (1 << args.l)
+        stage_bytes = {"scan": nbytes + (8.0 * keys_logged if partitioned else 16.0 * kmers_rank),
+                       "level1": 16.0 * keys_logged, "level2": 16.0 * keys_logged,
+                       "build": 8.0 * keys_logged + table_bytes}
+        names = {"scan": "scan_log_kernel" if partitioned else "count_fastq_kernel<1>",
+                 "level1": "partition_ring_kernel (level 1)", "level2": "partition_ring_kernel (level 2)",
+                 "build": "build_segments_kernel"}
+        stage_ms = {k2: stage[k2] / pieces for k2 in names}
+        dom = max(stage_ms, key=lambda k2: stage_ms[k2])   # the kernel a step spends most time in
+        kern_ms = stage_ms[dom]
+        kern_bytes = stage_bytes[dom]
         achieved = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         path_bytes = nbytes + 16.0 * kmers_rank
         path_ms = (scan_ms + count_ms + build_ms) / pieces
@@ -203,7 +218,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 prof = json.load(open(pmc))
-                traffic = prof.get("partitioned" if partitioned else "atomic", {}).get("hbm_bytes_per_launch")
+                pp = prof.get("partitioned" if partitioned else "atomic", {})
+                traffic = pp.get("stages", {}).get(dom) if partitioned else pp.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -219,11 +235,15 @@ def main():
                                        else ", per-GPU tables merged over RCCL all-to-all") if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
                        "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL"},
-            "roofline": {"bound": "hbm", "kernel": "scan_log_kernel" if partitioned else "count_fastq_kernel<1>",
+            "roofline": {"bound": "hbm", "kernel": names[dom],
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
                          "line_pass_ms": scan_ms / pieces, "partition_build_ms": build_ms / pieces,
+                         "stages": {k2: {"kernel": names[k2], "ms": stage_ms[k2],
+                                         "algorithmic_bytes": stage_bytes[k2],
+                                         "achieved": stage_bytes[k2] / (stage_ms[k2] * 1e-3) / 1e9 if stage_ms[k2] > 0 else 0.0}
+                                    for k2 in names if stage_ms[k2] > 0},
                          "whole_path": {"algorithmic_bytes": path_bytes, "device_ms": path_ms,
                                         "achieved": path_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
                                         "frac": (path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_ms > 0 else 0.0}},

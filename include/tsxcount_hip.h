@@ -135,6 +135,13 @@ int tsx_hip_set_timing(tsx_hip_map *m, int enable);
 int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
                        uint64_t *launches);
 /*
+ * The same accumulation split per stage: stage_ms[5] = line passes, scan kernel
+ * (count_fastq_kernel or scan_log_kernel), radix level 1 (offsets + partition),
+ * radix level 2, segment build; the last three are 0 on the atomic path.  Either
+ * get_* call resets the accumulation.
+ */
+int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64_t *launches);
+/*
  * Insert path of the FASTQ entry points: 0 = choose per call (partitioned when
  * the text is at least 1/32 of the table bytes and k <= 32), 1 = always the
  * atomic path (one 64-bit CAS per distinct key), 2 = always the partitioned

@@ -21,10 +21,13 @@ for path in ("partitioned", "atomic"):
         shutil.copy(f[0], os.path.join(DST, "round1_kernel_stats_%s.csv" % path))
 
 agg = collections.defaultdict(dict)
+per_dispatch = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> {dispatch id: value}
 for f in sorted(glob.glob(os.path.join(SRC, "pmc_partitioned_*", "*", "*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] = agg[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        d = per_dispatch[k][r["Counter_Name"]]
+        d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
 with open(os.path.join(DST, "round1_pmc_counters_partitioned.csv"), "w") as out:
     out.write("kernel,counter,sum_over_dispatches_of_one_bench_run(steps=1,warmup=0)\n")
     for k in sorted(agg):
@@ -49,6 +52,20 @@ for k, v in agg.items():
 scan = part["kernels"].get("tsx::scan_log_kernel", {})
 part["kernel"] = "tsx::scan_log_kernel"
 part["hbm_bytes_per_launch"] = scan.get("hbm_read_bytes", 0) + scan.get("hbm_write_bytes", 0)
+# bench.py stages: the partition kernel runs twice per step (level 1, then level 2), told apart by dispatch order
+def nth_dispatch_bytes(kernel, nth):
+    v = per_dispatch.get(kernel, {})
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        return None
+    rd = [v["FETCH_SIZE"][i] for i in sorted(v["FETCH_SIZE"])]
+    wr = [v["WRITE_SIZE"][i] for i in sorted(v["WRITE_SIZE"])]
+    if nth >= len(rd) or nth >= len(wr):
+        return None
+    return rd[nth] * 2048 + wr[nth] * 1024
+part["stages"] = {"scan": nth_dispatch_bytes("tsx::scan_log_kernel", 0),
+                  "level1": nth_dispatch_bytes("tsx::partition_ring_kernel", 0),
+                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel", 1),
+                  "build": nth_dispatch_bytes("tsx::build_segments_kernel", 0)}
 part["hbm_bytes_whole_path_per_step"] = tot_r + tot_w
 lc = agg.get("tsx::line_count_kernel", {})
 if "FETCH_SIZE" in lc:

@@ -99,6 +99,7 @@ def lib():
     L.tsx_hip_set_timing.argtypes = [vp, ci]
     L.tsx_hip_get_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_double), u64p]
+    L.tsx_hip_get_stage_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u64p]
     L.tsx_hip_set_path.argtypes = [vp, ci]
     L.tsx_hip_synth_fastq_device.argtypes = [u64, u64, u64, ci, vp, sz, u64p, u64p, u64p, ci, vp]
     _lib = L
@@ -263,6 +264,12 @@ class TSXHashMapHIP:
         _check(self._lib.tsx_hip_get_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
                                             ctypes.byref(n)))
         return a.value, b.value, c.value, int(n.value)
+
+    def get_stage_timing(self):
+        """({stage: ms}, pieces) since the last call; stages: line, scan, level1, level2, build."""
+        ms, n = (ctypes.c_double * 5)(), ctypes.c_uint64(0)
+        _check(self._lib.tsx_hip_get_stage_timing(self._h, ms, ctypes.byref(n)))
+        return dict(zip(("line", "scan", "level1", "level2", "build"), [float(x) for x in ms])), int(n.value)
 
     def set_path(self, path):
         """0 auto, 1 atomic, 2 partitioned (tsx_hip_set_path)."""

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
-    uint32_t capbits) {
+    uint32_t capbits, int dbg) {
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
@@ -181,8 +181,9 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     // a handful of hot keys (k-mers that occur once per read, thousands of times in all).
     // They are folded into a small LDS cache and reach the table through ONE atomic insert
     // per key and workgroup at the end, instead of one contended atomic per occurrence.
+    uint32_t spilled = 0;  // per thread; one atomic per wave at the end
     auto spill = [&](uint64_t key) {
-        atomicAdd(&p.stats[ST_FALLBACK], 1ULL);
+        ++spilled;
         const uint64_t kk = key ^ OVF_SALT;
         if (kk != 0) {
             uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         insert_key<1>(p, h, 1);
     };
     auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
+        if (dbg & 256) return;  // ablation: no stores
         if (at < lim) dst[at] = key;
         else spill(key);  // sub-list full
     };
@@ -205,8 +207,11 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             const uint32_t head = s_head[b];
             const uint32_t tail = min(s_tail[b], head + CAP);  // arrivals past the ring went out directly
             const uint32_t avail = tail - head;
-            const uint32_t nout = all ? avail : (avail & ~(uint32_t)(PART_FLUSH - 1));
             const unsigned long long at = s_cur[b];
+            // bursts end on a 128-B line of the destination: after a list's first (short) burst every
+            // store instruction of an octet writes one whole, aligned line
+            const unsigned long long end = (at + avail) & ~(unsigned long long)(PART_FLUSH - 1);
+            const uint32_t nout = all ? avail : (end > at ? (uint32_t)(end - at) : 0u);
             s_meta[b] = (at << 16) | ((unsigned long long)(head & cmask) << 8) | nout;
             s_head[b] = head + nout;
             s_tail[b] = tail;
@@ -214,6 +219,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         }
         lds_barrier();
         const uint32_t oct = tid >> 3, ol = tid & 7;  // (B)
+        if (dbg & 512) return;  // ablation: bookkeeping only
         for (uint32_t g0 = 0; g0 < nb; g0 += PART_ITER * (PART_NT / 8)) {
             unsigned long long meta[PART_ITER], lim[PART_ITER];
             uint64_t k0[PART_ITER], k1[PART_ITER];
@@ -292,6 +298,8 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         const uint64_t h[1] = {s_ovk[tid] ^ OVF_SALT};
         insert_key<1>(p, h, s_ovc[tid]);
     }
+    for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
+    if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
 }
 
 // Write offsets from the level-1 histograms hist[b * G + g] (bucket-major), two steps:

@@ -64,7 +64,7 @@ struct tsx_hip_map {
     // optional per-pass timing (HIP events on the launch stream)
     int timing = 0;
     int dbg = 0;                     // TSX_HIP_DEBUG: bit0 = skip the global insert (ablation builds only)
-    std::vector<hipEvent_t> ev;      // quads: before pass 1, before pass 3, after pass 3, after partition + build
+    std::vector<hipEvent_t> ev;      // six per piece: before pass 1, before pass 3, after pass 3, after level 1, level 2, build
     size_t ev_used = 0;
 };
 
@@ -497,7 +497,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.cpr2 = pl.b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / pl.nb1)) : 1;
     if (pl.b2) if (const char *e = getenv("TSX_HIP_CPR2")) pl.cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
     const uint64_t per_sub = maxrec / pl.nseg / pl.cpr2;
-    pl.cap_sub = even(per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64);
+    // multiple of 16 keys: every sub-list starts on a 128-B line
+    pl.cap_sub = (per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64 + 15) & ~15ULL;
     // buffer 0: key log, later the segment sub-lists of a two-level split; buffer 1: packed level-1 output
     const uint64_t keys_cap = own_log ? (uint64_t)g * pl.log_cap : maxrec;
     const size_t need0 = std::max<uint64_t>(own_log ? keys_cap : 0, pl.b2 ? (uint64_t)pl.nseg * pl.cpr2 * pl.cap_sub : 0) * 8;
@@ -535,7 +536,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
 // either src_cap apart with fills c_log (a key log) or at region_start/c_log (cuts of a
 // packed array); pl.d_hist must hold their level-1 histogram.
 static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_t *src,
-                               const unsigned long long *region_start, uint64_t src_cap, hipStream_t st) {
+                               const unsigned long long *region_start, uint64_t src_cap, hipStream_t st,
+                               hipEvent_t *ev = nullptr) {
     const TableParams &p = m->p;
     // ring depth: PART_FLUSH-1 keys may stay behind a flush, plus one batch of arrivals (mean = batch / nb)
     auto ring_bits = [](uint32_t nb) {
@@ -553,9 +555,10 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st, m->p, src,
                            region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u, m->d_buf[1],
                            (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
-                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits);
+                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg);
         HIP_TRY(hipGetLastError());
     }
+    if (ev) HIP_TRY(hipEventRecord(ev[3], st));
     const uint64_t *lists = m->d_buf[1];
     const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
     uint64_t lists_cap = 0;
@@ -566,10 +569,11 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            (const uint64_t *)m->d_buf[1], (const unsigned long long *)pl.c_bstart,
                            (const unsigned long long *)pl.c_bcnt, (uint64_t)0, pl.nb1, pl.cpr2, m->d_buf[0],
                            (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, pl.c_seg,
-                           pl.cap_sub, pl.nb2, (uint32_t)p.S, bits);
+                           pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg);
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
+    if (ev) HIP_TRY(hipEventRecord(ev[4], st));
     if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
         const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 16);
         int bnt = 1024;
@@ -601,10 +605,10 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     hipEvent_t *ev = nullptr;
     if (m->timing) {
-        if (m->ev_used + 4 > m->ev.size()) {
-            for (int i = 0; i < 4; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
+        if (m->ev_used + 6 > m->ev.size()) {
+            for (int i = 0; i < 6; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
         }
-        ev = &m->ev[m->ev_used]; m->ev_used += 4;
+        ev = &m->ev[m->ev_used]; m->ev_used += 6;
         HIP_TRY(hipEventRecord(ev[0], st));
     }
     const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
@@ -630,7 +634,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
                                           own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
         HIP_TRY(hipGetLastError());
-        if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
+        if (ev) for (int i = 2; i < 6; ++i) HIP_TRY(hipEventRecord(ev[i], st));
         return TSX_HIP_OK;
     }
 
@@ -662,10 +666,11 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(shard_counts, pl.c_bcnt, nown * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
     } else {
-        rc = run_partition_build(m, pl, m->d_buf[0], nullptr, pl.log_cap, st);
+        rc = run_partition_build(m, pl, m->d_buf[0], nullptr, pl.log_cap, st, ev);
         if (rc != TSX_HIP_OK) return rc;
     }
-    if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+    if (ev && shard_send) for (int i = 3; i < 6; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+    if (ev && !shard_send) HIP_TRY(hipEventRecord(ev[5], st));
     return TSX_HIP_OK;
 }
 
@@ -750,24 +755,32 @@ extern "C" int tsx_hip_set_timing(tsx_hip_map *m, int enable) {
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
-                                  uint64_t *launches) {
+extern "C" int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64_t *launches) {
     if (!m) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
-    double a = 0, b = 0, c = 0;
-    for (size_t i = 0; i + 4 <= m->ev_used; i += 4) {
-        HIP_TRY(hipEventSynchronize(m->ev[i + 3]));
-        float t1 = 0, t2 = 0, t3 = 0;
-        HIP_TRY(hipEventElapsedTime(&t1, m->ev[i], m->ev[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&t2, m->ev[i + 1], m->ev[i + 2]));
-        HIP_TRY(hipEventElapsedTime(&t3, m->ev[i + 2], m->ev[i + 3]));
-        a += t1; b += t2; c += t3;
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i + 6 <= m->ev_used; i += 6) {
+        HIP_TRY(hipEventSynchronize(m->ev[i + 5]));
+        for (int sgm = 0; sgm < 5; ++sgm) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, m->ev[i + sgm], m->ev[i + sgm + 1]));
+            acc[sgm] += t;
+        }
     }
-    if (line_ms) *line_ms = a;
-    if (count_ms) *count_ms = b;
-    if (build_ms) *build_ms = c;
-    if (launches) *launches = m->ev_used / 4;
+    if (stage_ms) for (int sgm = 0; sgm < 5; ++sgm) stage_ms[sgm] = acc[sgm];
+    if (launches) *launches = m->ev_used / 6;
     m->ev_used = 0;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
+                                  uint64_t *launches) {
+    double sgm[5];
+    const int rc = tsx_hip_get_stage_timing(m, sgm, launches);
+    if (rc != TSX_HIP_OK) return rc;
+    if (line_ms) *line_ms = sgm[0];
+    if (count_ms) *count_ms = sgm[1];
+    if (build_ms) *build_ms = sgm[2] + sgm[3] + sgm[4];
     return TSX_HIP_OK;
 }
 
