@@ -218,6 +218,53 @@ def test_partitioned_path_parity_with_oracle(T, k, l, s, reads):
     m.close()
 
 
+@pytest.mark.parametrize("k", list(range(8, 33)))
+def test_rolling_hash_every_one_limb_k(T, k):
+    """The scan kernel of the partitioned path hashes the first window of a 16-position strip with
+    the LUT and every further one with the sliding update table of x -> c*x in GF(2^2k); lookups
+    hash with the LUT.  Any disagreement (a wrong irreducible polynomial, a wrong roll table) loses
+    k-mers.  Every k whose key fits one limb and whose table can be partitioned, several seeds;
+    short ragged reads so that strips straddle line ends."""
+    rng = np.random.default_rng(1000 + k)
+    recs = []
+    for r in range(400):
+        n = int(rng.integers(1, 3 * k + 20))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+        recs.append(b"@r%d\n" % r + seq + b"\n+\n" + b"I" * n + b"\n")
+    text = b"".join(recs)
+    exp = python_counts(text, k)
+    kmers = T.encode_many(list(exp.keys()), k) if exp else np.zeros((0, 1), dtype=np.uint64)
+    want = np.array(list(exp.values()), dtype=np.uint64)
+    for seed in (1, 2, 77):
+        m = T.TSXHashMapHIP(15, 0, k, hash_seed=seed)
+        m.set_path("partitioned")
+        m.countFastq(text)
+        st = m.stats()
+        assert st["distinct"] == len(exp) and st["kmers_added"] == int(want.sum()) and st["insert_failures"] == 0
+        if len(exp):
+            assert np.array_equal(m.getKmerCounts(kmers), want)
+        m.close()
+
+
+def test_stage_timing_hooks(T):
+    from tsxcount_amd import synth
+    text = synth.fastq(5, 0, 3000)
+    m = T.TSXHashMapHIP(22, 0, 31)
+    m.set_path("partitioned")
+    m.set_timing(True)
+    m.countFastq(text)
+    stage, pieces = m.get_stage_timing()
+    assert pieces >= 1 and set(stage) == {"line", "scan", "level1", "level2", "build"}
+    assert stage["scan"] > 0 and stage["level1"] > 0 and stage["build"] > 0
+    assert stage["level2"] < 0.2 * stage["level1"]   # l=22: one radix level, two events back to back
+    m.set_path("atomic")
+    m.countFastq(text)
+    a, b, c, pieces = m.get_timing()
+    assert pieces >= 1 and b > 0 and c < 0.2 * b   # atomic path: the partition events are recorded back to back
+    m.set_timing(False)
+    m.close()
+
+
 def test_partitioned_path_golden_and_skew(T, golden_fastq, golden_counts):
     from tsxcount_amd import synth
     m = T.TSXHashMapHIP(26, 4, 14)

@@ -340,7 +340,7 @@ __device__ __attribute__((noinline)) void scan_side_insert(const TableParams *pk
 //     the wave and folded into the wave's 8-entry hot cache with their total;
 //   * the level-1 histogram of each region is kept in LDS (exact offsets downstream).
 // Regions and histogram columns are indexed by blockIdx.x * 4 + wave.
-__global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const uint8_t *buf, uint64_t n,
+__global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const uint8_t *buf, uint64_t n,
                                                          uint64_t own_end, int head_open, const uint32_t *tile_line,
                                                          uint64_t ntiles, int dbg, uint64_t *log, uint64_t log_cap,
                                                          unsigned long long *log_cnt, uint32_t *hist, uint32_t hist_nb,
@@ -455,75 +455,90 @@ __global__ __launch_bounds__(NT, 3) void scan_log_kernel(TableParams p, const ui
             const uint32_t w0 = codes32[tid + ws], w1 = (ws < 2u) ? codes32[tid + ws + 1] : 0u;
             inc = __funnelshift_r(w0, w1, sh);
         }
-        // Pass A: the 16 hashes of the strip, by rolling.  The lane also tracks the run of equal
-        // k-mers (homopolymer) that is still open when the strip ends: reads end in such runs,
-        // and a run covers whole strips.  Its length goes to the wave's hot cache below; equal
-        // neighbours anywhere else in the strip are simply logged one by one.
-        uint64_t hs[16];
-        uint32_t runlen = 0;
-        uint64_t runkey = 0;
+        // The strip is walked in two halves of 8 positions (the hash rolls on across them), each:
+        // Pass A: 8 hashes by rolling.  The lane also tracks the run of equal k-mers (homopolymer)
+        // that is still open when the half ends: reads end in such runs, and a run covers whole
+        // strips.  Its length goes to the wave's hot cache; equal neighbours anywhere else are
+        // simply logged one by one.
+        // Pass B: everything else goes to this wave's log region, one contiguous piece per position.
+        for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
+            const uint32_t vm8 = (vm >> j0) & 0xFFu;
+            if (__ballot(vm8 != 0u) == 0ULL) {   // nothing to log in this half: only roll on
+                if (j0 == 0) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            hs[j] = h;
-            const bool valid = (vm >> j) & 1u;
-            const bool eq = (j > 0) && valid && ((vm >> (j > 0 ? j - 1 : 0)) & 1u) && (h == runkey) && runlen;
-            if (eq) runlen += 1u;
-            else if (valid) { runlen = 1u; runkey = h; }
-            if (j < 15) {
-                const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
-                                     (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
-                h = (h >> 2) ^ s_roll[idx];
-            }
-        }
-        // the open run: positions [lv - runlen + 1, lv], lv = last valid position of the strip
-        uint32_t single = vm;
-        {
-            const bool hot = vm && runlen > 1u;
-            if (hot) {
-                const uint32_t lv = 31u - (uint32_t)__clz(vm);
-                single &= ~(((1u << runlen) - 1u) << (lv + 1u - runlen));
-            }
-            unsigned long long pend = __ballot(hot);
-            while (pend) {   // merge equal keys across the wave, then one hot-cache update per key
-                const int src = __builtin_ctzll(pend);
-                const uint64_t key = __shfl((unsigned long long)runkey, src, 64);
-                const bool mine = hot && runkey == key;
-                pend &= ~__ballot(mine);
-                uint32_t tot = mine ? runlen : 0u;
-                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                if (lane == src) {
-                    uint64_t *hkey = s_hot_key + wave * HOT_N;
-                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
-                    int at = -1;
-                    for (int q = 0; q < HOT_N; ++q)
-                        if (hcnt[q] && hkey[q] == key) { at = q; break; }
-                    if (at < 0)
-                        for (int q = 0; q < HOT_N; ++q)
-                            if (!hcnt[q]) { at = q; hkey[q] = key; break; }
-                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
-                    else side_insert(key, tot);
-                }
-            }
-        }
-        // Pass B: everything else goes to this wave's log region, one contiguous run per strip position
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const bool em = (single >> j) & 1u;
-            const unsigned long long mk = __ballot(em);
-            if (mk) {
-                if (em) {
-                    const uint64_t key = hs[j];
-                    const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
-                    if (at < cap32) {
-                        my_log[at] = key;
-                        const uint32_t hb = (hist_shift < 32u) ? __funnelshift_r((uint32_t)key, (uint32_t)(key >> 32), hist_shift)
-                                                               : ((uint32_t)(key >> 32) >> (hist_shift - 32u));
-                        atomicAdd(&my_hist[hb & (hist_nb - 1)], 1u);
-                    } else {
-                        side_insert(key, 1);  // region full: atomic path (or the exchanged list)
+                    for (int j = 0; j < 8; ++j) {
+                        const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
+                                             (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
+                        h = (h >> 2) ^ s_roll[idx];
                     }
                 }
-                fill += (uint32_t)__builtin_popcountll(mk);
+                continue;
+            }
+            uint64_t hs[8];
+            uint32_t runlen = 0;
+            uint64_t runkey = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                hs[j] = h;
+                const bool valid = (vm8 >> j) & 1u;
+                const bool eq = (j > 0) && valid && ((vm8 >> (j > 0 ? j - 1 : 0)) & 1u) && (h == runkey) && runlen;
+                if (eq) runlen += 1u;
+                else if (valid) { runlen = 1u; runkey = h; }
+                if (j0 + j < 15) {
+                    const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
+                                         (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
+                    h = (h >> 2) ^ s_roll[idx];
+                }
+            }
+            // the open run: positions [lv - runlen + 1, lv], lv = last valid position of the half
+            uint32_t single = vm8;
+            {
+                const bool hot = vm8 && runlen > 1u;
+                if (hot) {
+                    const uint32_t lv = 31u - (uint32_t)__clz(vm8);
+                    single &= ~(((1u << runlen) - 1u) << (lv + 1u - runlen));
+                }
+                unsigned long long pend = __ballot(hot);
+                while (pend) {   // merge equal keys across the wave, then one hot-cache update per key
+                    const int src = __builtin_ctzll(pend);
+                    const uint64_t key = __shfl((unsigned long long)runkey, src, 64);
+                    const bool mine = hot && runkey == key;
+                    pend &= ~__ballot(mine);
+                    uint32_t tot = mine ? runlen : 0u;
+                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                    if (lane == src) {
+                        uint64_t *hkey = s_hot_key + wave * HOT_N;
+                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                        int at = -1;
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (hcnt[q] && hkey[q] == key) { at = q; break; }
+                        if (at < 0)
+                            for (int q = 0; q < HOT_N; ++q)
+                                if (!hcnt[q]) { at = q; hkey[q] = key; break; }
+                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                        else side_insert(key, tot);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool em = (single >> j) & 1u;
+                const unsigned long long mk = __ballot(em);
+                if (mk) {
+                    if (em) {
+                        const uint64_t key = hs[j];
+                        const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
+                        if (at < cap32) {
+                            my_log[at] = key;
+                            const uint32_t hb = (hist_shift < 32u) ? __funnelshift_r((uint32_t)key, (uint32_t)(key >> 32), hist_shift)
+                                                                   : ((uint32_t)(key >> 32) >> (hist_shift - 32u));
+                            atomicAdd(&my_hist[hb & (hist_nb - 1)], 1u);
+                        } else {
+                            side_insert(key, 1);  // region full: atomic path (or the exchanged list)
+                        }
+                    }
+                    fill += (uint32_t)__builtin_popcountll(mk);
+                }
             }
         }
     }

@@ -29,7 +29,12 @@ static thread_local std::string g_last_error;
         }                                                                                \
     } while (0)
 
-static const int SCAN_WG_PER_CU = 5;  // scan_log_kernel workgroups per CU (LDS 22 KiB, 140 VGPRs)
+static int scan_wg_per_cu() {  // scan_log_kernel workgroups per CU: 4 are resident (128 VGPRs, 28 KiB LDS)
+    static int v = 0;
+    if (!v) { v = 4; if (const char *e = getenv("TSX_HIP_SCAN_WGS")) v = std::min(16, std::max(1, atoi(e))); }
+    return v;
+}
+#define SCAN_WG_PER_CU scan_wg_per_cu()
 static const size_t STAGE_PIECE_DEFAULT = (size_t)64 << 20;  // bytes of FASTQ per host piece
 
 struct tsx_hip_map {
