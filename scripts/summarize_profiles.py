@@ -16,13 +16,23 @@ DST = os.path.join(ROOT, "profiles")
 TEXT_BYTES = 2081065118
 
 for path in ("partitioned", "atomic"):
-    f = glob.glob(os.path.join(SRC, "trace_" + path, "*", "*_kernel_stats.csv"))
+    f = sorted(glob.glob(os.path.join(SRC, "trace_" + path, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if f:
-        shutil.copy(f[0], os.path.join(DST, "round1_kernel_stats_%s.csv" % path))
+        shutil.copy(f[-1], os.path.join(DST, "round1_kernel_stats_%s.csv" % path))
 
 agg = collections.defaultdict(dict)
 per_dispatch = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> {dispatch id: value}
-for f in sorted(glob.glob(os.path.join(SRC, "pmc_partitioned_*", "*", "*_counter_collection.csv"))):
+def newest(pattern):
+    """gpurun merges every run's files into gpurun_out/: keep the newest file of each profile directory."""
+    best = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(os.path.dirname(f))
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return [best[d] for d in sorted(best)]
+
+
+for f in newest(os.path.join(SRC, "pmc_partitioned_*", "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] = agg[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
