@@ -3,12 +3,15 @@
 // Random 64-bit global atomics top out at ~17 G/s on MI355X whatever the
 // footprint (profiles/round1_atomics_ubench.txt), so for large inputs the table
 // is not updated in place.  Instead:
-//   count_fastq_kernel   writes hashed keys to a per-workgroup log (no atomics)
-//   partition_kernel     x1 or x2: radix-scatters keys by the high bits of their
-//                        home slot into one list per table segment, through
-//                        LDS staging and 64/128-B bursts
-//   build_segments_kernel one workgroup per 2^S-slot segment: segment in LDS,
-//                        inserts with LDS atomics, streamed back once
+//   scan_log_kernel        (tsx_kernels.h) writes hashed keys to one log region per
+//                          wave and keeps a level-1 histogram per region (no atomics)
+//   offsets_*_kernel       exclusive scan of the histograms -> exact write offsets
+//   partition_ring_kernel  x1 or x2: radix-scatters keys by the high bits of their
+//                          home slot into one list per table segment, through LDS
+//                          ring staging and 128-B bursts
+//   build_segments_kernel  one workgroup per 2^S-slot segment: segment in LDS,
+//                          inserts with LDS atomics, streamed back once
+//   split_owner_kernel, hist_kernel, add_hashed_kernel: the sharded (multi-GPU) legs
 // All HBM traffic is sequential.  Anything that does not fit a list (skewed
 // data) falls back to insert_key(), i.e. the atomic path: slower, same result.
 #pragma once
@@ -19,115 +22,6 @@ namespace tsx {
 constexpr int PART_NT = 256;
 constexpr int PART_RPT = 8;      // keys per thread per batch
 constexpr int PART_FLUSH = 16;   // keys per burst (128 B = one L2 line)
-
-// One radix level.  Source = `nregions` regions of `src_cap` records each
-// (`src_cnt[r]` valid, clamped to src_cap).  Destination lists have `dst_cap`
-// records; list index = (prefix ? r * nb : 0) + ((key >> shift) & (nb - 1)).
-// gridDim.x = nregions * cpr: workgroup (r, c) takes batches c, c+cpr, ...
-__global__ __launch_bounds__(PART_NT) void partition_kernel(TableParams p, const uint64_t *src,
-                                                            const unsigned long long *src_cnt, uint64_t src_cap,
-                                                            uint32_t nregions, uint32_t cpr, uint64_t *dst,
-                                                            unsigned long long *dst_cnt, uint64_t dst_cap,
-                                                            uint32_t nb, uint32_t shift, int prefix, uint32_t cap,
-                                                            int dbg) {
-    extern __shared__ uint64_t s_part[];       // nb * cap staged keys, then per list: count, flush size, offset
-    uint64_t *s_stage = s_part;
-    uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_part + (size_t)nb * cap);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t r = blockIdx.x / cpr, c = blockIdx.x % cpr;
-    if (r >= nregions) return;
-    for (uint32_t b = tid; b < nb; b += PART_NT) s_cnt[b] = 0;
-    __syncthreads();
-    const uint64_t n = min((uint64_t)src_cnt[r], src_cap);
-    const uint64_t *in = src + (uint64_t)r * src_cap;
-    const uint64_t list0 = prefix ? (uint64_t)r * nb : 0;
-    constexpr uint64_t BATCH_REC = (uint64_t)PART_NT * PART_RPT;
-
-    auto put_direct = [&](uint64_t key, uint32_t b) {
-        const uint64_t li = list0 + b;
-        const unsigned long long at = atomicAdd(&dst_cnt[li], 1ULL);
-        if (at < dst_cap) dst[li * dst_cap + at] = key;
-        else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }
-    };
-    // Flush, two steps.  (1) thread b reserves room for list b with one returning
-    // atomic on its cursor: all lists in ONE instruction per wave, its latency is paid
-    // once per batch.  (2) 8 consecutive lanes serve one list, lane q of the octet
-    // moves staged key q (+8, +16): every store instruction writes whole 64-B sectors.
-    uint32_t *s_out = s_cnt + nb;                                          // keys to flush per list
-    unsigned long long *s_at = reinterpret_cast<unsigned long long *>(s_cnt + 2 * nb);  // reserved offsets
-    auto flush = [&](bool all) {
-        for (uint32_t b = tid; b < nb; b += PART_NT) {
-            const uint32_t have = min(s_cnt[b], cap);
-            const uint32_t nout = all ? have : (have & ~(uint32_t)(PART_FLUSH - 1));
-            s_out[b] = nout;
-            if (nout) s_at[b] = (dbg & 128) ? 0ULL : atomicAdd(&dst_cnt[list0 + b], (unsigned long long)nout);
-        }
-        __syncthreads();
-        const uint32_t oct = tid >> 3, ol = tid & 7;
-        for (uint32_t b = oct; b < nb; b += PART_NT / 8) {
-            const uint32_t nout = s_out[b];
-            if (nout == 0) continue;                       // uniform inside the octet
-            const uint32_t have = min(s_cnt[b], cap);
-            const unsigned long long at = s_at[b];
-            uint64_t *out = dst + (list0 + b) * dst_cap;
-            uint64_t *st = s_stage + (size_t)b * cap;
-            uint64_t keep[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const uint32_t q = ol + 8 * u;
-                if (q < nout) {
-                    const uint64_t key = st[q];
-                    if (at + q < dst_cap) out[at + q] = key;
-                    else { const uint64_t h[1] = {key}; insert_key<1>(p, h, 1); }
-                }
-                // staged keys beyond nout move to the front (at most 7 of them)
-                const uint32_t qs = nout + ol + 8 * u;
-                keep[u] = (qs < have) ? st[qs] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const uint32_t qs = nout + ol + 8 * u;
-                if (qs < have) st[ol + 8 * u] = keep[u];
-            }
-            if (ol == 0) s_cnt[b] = have - nout;
-        }
-    };
-
-    // software pipeline: the next batch's keys are in flight while this one is staged
-    uint64_t cur[PART_RPT], nxt[PART_RPT];
-    const uint64_t stride = (uint64_t)cpr * BATCH_REC;
-    uint64_t base = (uint64_t)c * BATCH_REC;
-#pragma unroll
-    for (int q = 0; q < PART_RPT; ++q) {
-        const uint64_t i = base + (uint64_t)q * PART_NT + tid;
-        cur[q] = (i < n) ? in[i] : 0;
-    }
-    for (; base < n; base += stride) {
-        const uint64_t nbase = base + stride;
-#pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) {
-            const uint64_t i = nbase + (uint64_t)q * PART_NT + tid;
-            nxt[q] = (i < n) ? in[i] : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * PART_NT + tid;
-            if (i < n) {
-                const uint64_t key = cur[q];
-                const uint32_t b = (uint32_t)(key >> shift) & (nb - 1);
-                const uint32_t slot = atomicAdd(&s_cnt[b], 1u);
-                if (slot < cap) s_stage[(size_t)b * cap + slot] = key;
-                else put_direct(key, b);
-            }
-        }
-        __syncthreads();
-        flush(false);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) cur[q] = nxt[q];
-    }
-    flush(true);
-}
 
 // Atomic-free radix level.  A workgroup (r, c) takes every cpr-th batch of source
 // region r and owns the write cursors of its destination lists, which therefore
