@@ -55,7 +55,9 @@ struct tsx_hip_map {
     // host staging
     uint8_t *h_stage[2] = {nullptr, nullptr};
     uint8_t *d_stage[2] = {nullptr, nullptr};
-    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};   // kernels that read d_stage[i] have finished
+    hipEvent_t stage_in[2] = {nullptr, nullptr};     // the H2D copy into d_stage[i] has finished
+    hipStream_t copy_stream = nullptr;               // H2D copies of the host entry point
     size_t stage_bytes = 0;
     size_t piece = STAGE_PIECE_DEFAULT;  // TSX_HIP_PIECE_BYTES overrides (tests exercise piece seams)
     bool piece_fixed = false;
@@ -398,7 +400,9 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
         if (m->h_stage[i]) (void)hipHostFree(m->h_stage[i]);
         if (m->d_stage[i]) (void)hipFree(m->d_stage[i]);
         if (m->stage_done[i]) (void)hipEventDestroy(m->stage_done[i]);
+        if (m->stage_in[i]) (void)hipEventDestroy(m->stage_in[i]);
     }
+    if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
@@ -830,22 +834,32 @@ static int ensure_staging(tsx_hip_map *m, size_t n) {
         if (m->h_stage[i]) { HIP_TRY(hipHostFree(m->h_stage[i])); m->h_stage[i] = nullptr; }
         if (m->d_stage[i]) { HIP_TRY(hipFree(m->d_stage[i])); m->d_stage[i] = nullptr; }
         if (m->stage_done[i]) { HIP_TRY(hipEventDestroy(m->stage_done[i])); m->stage_done[i] = nullptr; }
+        if (m->stage_in[i]) { HIP_TRY(hipEventDestroy(m->stage_in[i])); m->stage_in[i] = nullptr; }
     }
+    if (!m->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
     m->stage_bytes = 0;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipHostMalloc((void **)&m->h_stage[i], bytes, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&m->d_stage[i], bytes));
         HIP_TRY(hipEventCreateWithFlags(&m->stage_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->stage_in[i], hipEventDisableTiming));
     }
     m->stage_bytes = bytes;
     return TSX_HIP_OK;
 }
 
-// Pageable -> pinned staging copy on a few host threads: one thread moves ~10 GB/s,
-// the PCIe link ~55 GB/s.
+// Pageable -> pinned staging copy on several host threads: one thread moves ~10 GB/s,
+// the PCIe link ~55 GB/s.  TSX_HIP_COPY_THREADS overrides the default (hardware threads - 2,
+// at most 12).
 static void parallel_memcpy(uint8_t *dst, const char *src, size_t len) {
-    const size_t MIN_PER_THREAD = (size_t)16 << 20;
-    unsigned nthreads = (unsigned)std::min<size_t>(6, len / MIN_PER_THREAD);
+    static unsigned maxt = 0;
+    if (!maxt) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        maxt = std::min(12u, std::max(2u, hw > 2 ? hw - 2 : 2u));
+        if (const char *e = getenv("TSX_HIP_COPY_THREADS")) maxt = (unsigned)std::min(64, std::max(1, atoi(e)));
+    }
+    const size_t MIN_PER_THREAD = (size_t)8 << 20;
+    unsigned nthreads = (unsigned)std::min<size_t>(maxt, len / MIN_PER_THREAD);
     if (nthreads <= 1) { memcpy(dst, src, len); return; }
     std::vector<std::thread> th;
     const size_t per = ((len / nthreads) + 4095) & ~(size_t)4095;
@@ -872,9 +886,13 @@ extern "C" int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t
     for (size_t off = 0; off < n; off += m->piece, buf ^= 1) {
         const size_t own = std::min(m->piece, n - off);
         const size_t len = std::min(own + halo, n - off);
+        // three legs overlap: this piece's host copy, the previous piece's H2D copy (its own stream)
+        // and the kernels of the piece before that
         if (used[buf]) HIP_TRY(hipEventSynchronize(m->stage_done[buf]));
         parallel_memcpy(m->h_stage[buf], text + off, len);
-        HIP_TRY(hipMemcpyAsync(m->d_stage[buf], m->h_stage[buf], len, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(m->d_stage[buf], m->h_stage[buf], len, hipMemcpyHostToDevice, m->copy_stream));
+        HIP_TRY(hipEventRecord(m->stage_in[buf], m->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(st, m->stage_in[buf], 0));
         const int head_open = (off > 0 && text[off - 1] != '\n') ? 1 : 0;
         rc = run_fastq_piece(m, m->d_stage[buf], len, own, head_open, st);
         if (rc != TSX_HIP_OK) return rc;
