@@ -107,7 +107,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29671")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # stdout carries ONE JSON line: RCCL's start-up banner ("RCCL version : ...") goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            if args.backend == "nccl" and torch.cuda.is_available():
+                torch.cuda.set_device(local_rank)
+                warm = torch.zeros((1,), dtype=torch.int64, device="cuda")
+                dist.all_reduce(warm)   # communicator set-up happens (and prints) here
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.backend == "gloo":
@@ -240,6 +254,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": kern_bytes,
                          "line_pass_ms": scan_ms / pieces, "partition_build_ms": build_ms / pieces,
+                         "exchange_gap_ms": stage["gap"] / pieces,
                          "stages": {k2: {"kernel": names[k2], "ms": stage_ms[k2],
                                          "algorithmic_bytes": stage_bytes[k2],
                                          "achieved": stage_bytes[k2] / (stage_ms[k2] * 1e-3) / 1e9 if stage_ms[k2] > 0 else 0.0}

@@ -266,10 +266,11 @@ class TSXHashMapHIP:
         return a.value, b.value, c.value, int(n.value)
 
     def get_stage_timing(self):
-        """({stage: ms}, pieces) since the last call; stages: line, scan, level1, level2, build."""
-        ms, n = (ctypes.c_double * 5)(), ctypes.c_uint64(0)
+        """({stage: ms}, pieces) since the last call; stages: line, scan, level1, level2, build, gap
+        (gap = scan end to partition start: the owner split and the key exchange of a sharded run)."""
+        ms, n = (ctypes.c_double * 6)(), ctypes.c_uint64(0)
         _check(self._lib.tsx_hip_get_stage_timing(self._h, ms, ctypes.byref(n)))
-        return dict(zip(("line", "scan", "level1", "level2", "build"), [float(x) for x in ms])), int(n.value)
+        return dict(zip(("line", "scan", "level1", "level2", "build", "gap"), [float(x) for x in ms])), int(n.value)
 
     def set_path(self, path):
         """0 auto, 1 atomic, 2 partitioned (tsx_hip_set_path)."""

@@ -71,7 +71,10 @@ struct tsx_hip_map {
     // optional per-pass timing (HIP events on the launch stream)
     int timing = 0;
     int dbg = 0;                     // TSX_HIP_DEBUG: bit0 = skip the global insert (ablation builds only)
-    std::vector<hipEvent_t> ev;      // six per piece: before pass 1, before pass 3, after pass 3, after level 1, level 2, build
+    std::vector<hipEvent_t> ev;      // seven per piece: before pass 1, before pass 3, after pass 3, start of the
+                                     // partition phase (later than the scan's end only in a sharded run: the
+                                     // exchange lies between), after level 1, level 2, build
+    long ev_open = -1;               // tuple of a shard scan whose partition phase has not run yet
     size_t ev_used = 0;
 };
 
@@ -567,7 +570,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg);
         HIP_TRY(hipGetLastError());
     }
-    if (ev) HIP_TRY(hipEventRecord(ev[3], st));
+    if (ev) HIP_TRY(hipEventRecord(ev[4], st));
     const uint64_t *lists = m->d_buf[1];
     const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
     uint64_t lists_cap = 0;
@@ -582,7 +585,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
-    if (ev) HIP_TRY(hipEventRecord(ev[4], st));
+    if (ev) HIP_TRY(hipEventRecord(ev[5], st));
     if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
         const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 16);
         int bnt = 1024;
@@ -614,10 +617,10 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     hipEvent_t *ev = nullptr;
     if (m->timing) {
-        if (m->ev_used + 6 > m->ev.size()) {
-            for (int i = 0; i < 6; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
+        if (m->ev_used + 7 > m->ev.size()) {
+            for (int i = 0; i < 7; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
         }
-        ev = &m->ev[m->ev_used]; m->ev_used += 6;
+        ev = &m->ev[m->ev_used]; m->ev_used += 7;
         HIP_TRY(hipEventRecord(ev[0], st));
     }
     const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
@@ -643,7 +646,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
                                           own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
         HIP_TRY(hipGetLastError());
-        if (ev) for (int i = 2; i < 6; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+        if (ev) for (int i = 2; i < 7; ++i) HIP_TRY(hipEventRecord(ev[i], st));
         return TSX_HIP_OK;
     }
 
@@ -661,7 +664,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
                        shard_send ? nown : pl.nb1, (uint32_t)(shard_send ? p.l : p.l - pl.b1), hot.keys, hot.cnts, hot.cap,
                        hot.n);
     HIP_TRY(hipGetLastError());
-    if (ev) HIP_TRY(hipEventRecord(ev[2], st));
+    if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
     if (shard_send) {
         // level 0: split every log region by owner into the caller's send buffer (exact offsets)
         if ((uint64_t)greg * pl.log_cap > shard_cap) return TSX_HIP_ERANGE;
@@ -678,8 +681,11 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         rc = run_partition_build(m, pl, m->d_buf[0], nullptr, pl.log_cap, st, ev);
         if (rc != TSX_HIP_OK) return rc;
     }
-    if (ev && shard_send) for (int i = 3; i < 6; ++i) HIP_TRY(hipEventRecord(ev[i], st));
-    if (ev && !shard_send) HIP_TRY(hipEventRecord(ev[5], st));
+    if (ev && shard_send) {   // the partition phase follows in tsx_hip_shard_build_device, which records 3..6 again
+        for (int i = 3; i < 7; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+        m->ev_open = (long)(ev - m->ev.data());
+    }
+    if (ev && !shard_send) HIP_TRY(hipEventRecord(ev[6], st));
     return TSX_HIP_OK;
 }
 
@@ -730,11 +736,19 @@ extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, 
     PartPlan pl;
     int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl);
     if (rc != TSX_HIP_OK) return rc;
+    hipEvent_t *ev = nullptr;
+    if (m->timing && m->ev_open >= 0 && (size_t)m->ev_open + 7 <= m->ev_used) {
+        ev = &m->ev[(size_t)m->ev_open];
+        HIP_TRY(hipEventRecord(ev[3], st));   // the histogram of the received keys counts as level 1
+    }
+    m->ev_open = -1;
     const uint64_t region_len = (n_keys + g - 1) / g;
     hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, (const uint64_t *)dev_keys, (uint64_t)n_keys, region_len,
                        (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1), pl.d_hist, pl.c_rstart, pl.c_log);
     HIP_TRY(hipGetLastError());
-    return run_partition_build(m, pl, (const uint64_t *)dev_keys, pl.c_rstart, 0, st);
+    rc = run_partition_build(m, pl, (const uint64_t *)dev_keys, pl.c_rstart, 0, st, ev);
+    if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[6], st));
+    return rc;
 }
 
 extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
@@ -767,24 +781,26 @@ extern "C" int tsx_hip_set_timing(tsx_hip_map *m, int enable) {
 extern "C" int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64_t *launches) {
     if (!m) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
-    double acc[5] = {0, 0, 0, 0, 0};
-    for (size_t i = 0; i + 6 <= m->ev_used; i += 6) {
-        HIP_TRY(hipEventSynchronize(m->ev[i + 5]));
-        for (int sgm = 0; sgm < 5; ++sgm) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    static const int from[6] = {0, 1, 3, 4, 5, 2}, to[6] = {1, 2, 4, 5, 6, 3};  // line, scan, level 1, level 2, build, gap
+    for (size_t i = 0; i + 7 <= m->ev_used; i += 7) {
+        HIP_TRY(hipEventSynchronize(m->ev[i + 6]));
+        for (int sgm = 0; sgm < 6; ++sgm) {
             float t = 0;
-            HIP_TRY(hipEventElapsedTime(&t, m->ev[i + sgm], m->ev[i + sgm + 1]));
+            HIP_TRY(hipEventElapsedTime(&t, m->ev[i + from[sgm]], m->ev[i + to[sgm]]));
             acc[sgm] += t;
         }
     }
-    if (stage_ms) for (int sgm = 0; sgm < 5; ++sgm) stage_ms[sgm] = acc[sgm];
-    if (launches) *launches = m->ev_used / 6;
+    if (stage_ms) for (int sgm = 0; sgm < 6; ++sgm) stage_ms[sgm] = acc[sgm];
+    if (launches) *launches = m->ev_used / 7;
     m->ev_used = 0;
+    m->ev_open = -1;
     return TSX_HIP_OK;
 }
 
 extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
                                   uint64_t *launches) {
-    double sgm[5];
+    double sgm[6];
     const int rc = tsx_hip_get_stage_timing(m, sgm, launches);
     if (rc != TSX_HIP_OK) return rc;
     if (line_ms) *line_ms = sgm[0];
