@@ -246,6 +246,17 @@ def test_rolling_hash_every_one_limb_k(T, k):
         m.close()
 
 
+def test_log_region_overflow_takes_the_side_path(T, monkeypatch):
+    """A wave's key-log region that fills up hands the rest of its keys to the atomic path
+    (scan_side_insert): forced here by shrinking the regions to 64 keys."""
+    from tsxcount_amd import synth
+    text = synth.fastq(9, 0, 600)
+    monkeypatch.setenv("TSX_HIP_LOG_CAP", "64")
+    assert_same_as_oracle(T, text, 31, 20, 0, path="partitioned")
+    assert_same_as_oracle(T, synth.fastq(10, 0, 100), 14, 18, 4, path="partitioned")
+    monkeypatch.delenv("TSX_HIP_LOG_CAP")
+
+
 def test_stage_timing_hooks(T):
     from tsxcount_amd import synth
     text = synth.fastq(5, 0, 3000)

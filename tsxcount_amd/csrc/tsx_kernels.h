@@ -520,24 +520,39 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
                     }
                 }
             }
+            if (fill + 64u * 8u <= cap32) {   // the usual case: the region has room for whatever this half logs
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool em = (single >> j) & 1u;
-                const unsigned long long mk = __ballot(em);
-                if (mk) {
-                    if (em) {
-                        const uint64_t key = hs[j];
-                        const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
-                        if (at < cap32) {
-                            my_log[at] = key;
-                            const uint32_t hb = (hist_shift < 32u) ? __funnelshift_r((uint32_t)key, (uint32_t)(key >> 32), hist_shift)
-                                                                   : ((uint32_t)(key >> 32) >> (hist_shift - 32u));
-                            atomicAdd(&my_hist[hb & (hist_nb - 1)], 1u);
-                        } else {
-                            side_insert(key, 1);  // region full: atomic path (or the exchanged list)
+                for (int j = 0; j < 8; ++j) {
+                    const bool em = (single >> j) & 1u;
+                    const unsigned long long mk = __ballot(em);
+                    if (mk) {
+                        if (em) {
+                            const uint64_t key = hs[j];
+                            my_log[fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = key;
+                            atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
                         }
+                        fill += (uint32_t)__builtin_popcountll(mk);
                     }
-                    fill += (uint32_t)__builtin_popcountll(mk);
+                }
+            } else {
+                for (int j = 0; j < 8; ++j) {
+                    const bool em = (single >> j) & 1u;
+                    const unsigned long long mk = __ballot(em);
+                    if (mk) {
+                        if (em) {
+                            uint64_t key = hs[0];
+#pragma unroll
+                            for (int t = 1; t < 8; ++t) key = (j == t) ? hs[t] : key;
+                            const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
+                            if (at < cap32) {
+                                my_log[at] = key;
+                                atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
+                            } else {
+                                side_insert(key, 1);  // region full: atomic path (or the exchanged list)
+                            }
+                        }
+                        fill += (uint32_t)__builtin_popcountll(mk);
+                    }
                 }
             }
         }

@@ -505,6 +505,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.hist_nb = hist_nb_override ? hist_nb_override : pl.nb1;
     auto even = [](uint64_t v) { return (v + 1) & ~1ULL; };
     pl.log_cap = even(maxrec / g + maxrec / g / 3 + 2048);
+    if (const char *e = getenv("TSX_HIP_LOG_CAP")) pl.log_cap = even(std::max(16, atoi(e)));  // tests: force region overflow
     // level 2 runs cpr2 workgroups per level-1 bucket; each owns one sub-list per segment
     pl.cpr2 = pl.b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / pl.nb1)) : 1;
     if (pl.b2) if (const char *e = getenv("TSX_HIP_CPR2")) pl.cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
