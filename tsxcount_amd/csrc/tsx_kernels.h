@@ -356,6 +356,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hist[(NT / 64) * 512];  // level-1 fan-out <= 512
     __shared__ uint64_t s_roll[64];
+    __shared__ uint64_t s_homh[4];     // hashes of the four homopolymer k-mers
     extern __shared__ uint64_t s_lut[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -363,6 +364,12 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
     for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
     if (tid < 64) s_roll[tid] = p.roll[tid];
+    if (tid < 4) {   // straight from the global LUT: s_lut is not complete before the first barrier
+        const uint64_t x[1] = {(0x5555555555555555ULL * (uint64_t)tid) & p.top_mask};
+        uint64_t hh[1];
+        hash_apply<1>(p, p.lut, x, hh);
+        s_homh[tid] = hh[0];
+    }
     if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
     if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
     if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
@@ -455,15 +462,67 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
             const uint32_t w0 = codes32[tid + ws], w1 = (ws < 2u) ? codes32[tid + ws + 1] : 0u;
             inc = __funnelshift_r(w0, w1, sh);
         }
-        // The strip is walked in two halves of 8 positions (the hash rolls on across them), each:
-        // Pass A: 8 hashes by rolling.  The lane also tracks the run of equal k-mers (homopolymer)
-        // that is still open when the half ends: reads end in such runs, and a run covers whole
-        // strips.  Its length goes to the wave's hot cache; equal neighbours anywhere else are
-        // simply logged one by one.
-        // Pass B: everything else goes to this wave's log region, one contiguous piece per position.
+        // Homopolymer k-mers (all k bases equal) are the one kind of k-mer that repeats back to back --
+        // the A-tails of reads -- and there are only four of them.  They are found on the 2-bit codes,
+        // not on the hashes: "base i differs from base i+1" is a bit per base, OR-smeared over k-1 bases.
+        // Their occurrences are counted per lane, summed over the wave and folded into the wave's hot
+        // cache under the four precomputed hashes; everything else is logged.
+        uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
+        {
+            const uint64_t lo = (uint64_t)cw0 | ((uint64_t)codes32[tid + 1] << 32), hi = codes32[tid + 2];
+            const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
+            uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
+            uint32_t span = 1;   // bases covered by the smear so far; k - 1 adjacent pairs must agree
+            while (span * 2 <= k - 1) {
+                const uint32_t sh = 2u * span;
+                rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                rhi |= rhi >> sh;
+                span *= 2;
+            }
+            if (span < k - 1) {
+                const uint32_t sh = 2u * (k - 1 - span);
+                rlo |= (rlo >> sh) | (rhi << (64u - sh));
+            }
+            uint32_t x = ~(uint32_t)rlo & 0x55555555u;   // even bits -> 16 contiguous bits
+            x = (x | (x >> 1)) & 0x33333333u;
+            x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+            x = (x | (x >> 4)) & 0x00FF00FFu;
+            homm = (x | (x >> 8)) & 0xFFFFu;
+        }
+        const uint32_t hv = vm & homm;
+        const uint32_t single = vm & ~homm;
+        if (__ballot(hv != 0u)) {
+            for (uint32_t b = 0; b < 4; ++b) {   // which of the four: the base at the position
+                uint32_t e = cw0 ^ (0x55555555u * b);
+                uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
+                y = (y | (y >> 1)) & 0x33333333u;
+                y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+                y = (y | (y >> 4)) & 0x00FF00FFu;
+                y = (y | (y >> 8)) & 0xFFFFu;
+                uint32_t tot = (uint32_t)__popc(hv & y);
+                if (__ballot(tot != 0u) == 0ULL) continue;
+                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                if (lane == 0) {
+                    const uint64_t key = s_homh[b];
+                    uint64_t *hkey = s_hot_key + wave * HOT_N;
+                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                    int at = -1;
+                    for (int q = 0; q < HOT_N; ++q)
+                        if (hcnt[q] && hkey[q] == key) { at = q; break; }
+                    if (at < 0)
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (!hcnt[q]) { at = q; hkey[q] = key; break; }
+                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                    else side_insert(key, tot);
+                }
+            }
+        }
+        // The strip is walked in two halves of 8 positions (the hash rolls on across them): pass A
+        // rolls and keeps the 8 hashes, pass B appends them to this wave's log region, one contiguous
+        // piece per position.
         for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
-            const uint32_t vm8 = (vm >> j0) & 0xFFu;
-            if (__ballot(vm8 != 0u) == 0ULL) {   // nothing to log in this half: only roll on
+            const uint32_t s8 = (single >> j0) & 0xFFu;
+            if (__ballot(s8 != 0u) == 0ULL) {   // nothing to log in this half: only roll on
                 if (j0 == 0) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -475,55 +534,19 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
                 continue;
             }
             uint64_t hs[8];
-            uint32_t runlen = 0;
-            uint64_t runkey = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 hs[j] = h;
-                const bool valid = (vm8 >> j) & 1u;
-                const bool eq = (j > 0) && valid && ((vm8 >> (j > 0 ? j - 1 : 0)) & 1u) && (h == runkey) && runlen;
-                if (eq) runlen += 1u;
-                else if (valid) { runlen = 1u; runkey = h; }
                 if (j0 + j < 15) {
                     const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
                                          (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
                     h = (h >> 2) ^ s_roll[idx];
                 }
             }
-            // the open run: positions [lv - runlen + 1, lv], lv = last valid position of the half
-            uint32_t single = vm8;
-            {
-                const bool hot = vm8 && runlen > 1u;
-                if (hot) {
-                    const uint32_t lv = 31u - (uint32_t)__clz(vm8);
-                    single &= ~(((1u << runlen) - 1u) << (lv + 1u - runlen));
-                }
-                unsigned long long pend = __ballot(hot);
-                while (pend) {   // merge equal keys across the wave, then one hot-cache update per key
-                    const int src = __builtin_ctzll(pend);
-                    const uint64_t key = __shfl((unsigned long long)runkey, src, 64);
-                    const bool mine = hot && runkey == key;
-                    pend &= ~__ballot(mine);
-                    uint32_t tot = mine ? runlen : 0u;
-                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                    if (lane == src) {
-                        uint64_t *hkey = s_hot_key + wave * HOT_N;
-                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
-                        int at = -1;
-                        for (int q = 0; q < HOT_N; ++q)
-                            if (hcnt[q] && hkey[q] == key) { at = q; break; }
-                        if (at < 0)
-                            for (int q = 0; q < HOT_N; ++q)
-                                if (!hcnt[q]) { at = q; hkey[q] = key; break; }
-                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
-                        else side_insert(key, tot);
-                    }
-                }
-            }
             if (fill + 64u * 8u <= cap32) {   // the usual case: the region has room for whatever this half logs
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const bool em = (single >> j) & 1u;
+                    const bool em = (s8 >> j) & 1u;
                     const unsigned long long mk = __ballot(em);
                     if (mk) {
                         if (em) {
@@ -536,7 +559,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
                 }
             } else {
                 for (int j = 0; j < 8; ++j) {
-                    const bool em = (single >> j) & 1u;
+                    const bool em = (s8 >> j) & 1u;
                     const unsigned long long mk = __ballot(em);
                     if (mk) {
                         if (em) {
