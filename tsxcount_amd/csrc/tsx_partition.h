@@ -38,6 +38,32 @@ constexpr int PART_FLUSH = 16;   // keys per burst (128 B = one L2 line)
 // 128-B line; 64-B bursts cost 0.8 ms more in level 1) and where; (B) 8 consecutive
 // lanes per list copy them, with the LDS reads of all lists an octet serves issued
 // before the first store.
+// What does not fit a destination list (level 2 sub-lists under skew): almost always a handful of hot
+// keys (k-mers that occur once per read, thousands of times in all).  They are folded into a small LDS
+// cache and reach the table through ONE atomic insert per key and workgroup at the end, instead of one
+// contended atomic per occurrence.  Out of line, fed from the kernel-argument segment: the slow path and
+// insert_key() would otherwise be inlined at every store of the flush and serialise the scatter.
+constexpr uint32_t OVF_N = 64;
+constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
+__device__ __attribute__((noinline)) void part_spill(const TableParams *pk, uint64_t key, uint64_t *ovk, uint32_t *ovc) {
+    const uint64_t kk = key ^ OVF_SALT;
+    if (kk != 0) {
+        uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
+        for (int pr = 0; pr < 4; ++pr) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&ovk[slot]), 0ULL,
+                                                     (unsigned long long)kk);
+            if (old == 0ULL || old == kk) { atomicAdd(&ovc[slot], 1u); return; }
+            slot = (slot + 1) & (OVF_N - 1);
+        }
+    }
+    const uint64_t h[1] = {key};
+    insert_key<1>(*pk, h, 1);
+}
+__device__ __attribute__((noinline)) void part_insert(const TableParams *pk, uint64_t key, uint64_t d) {
+    const uint64_t h[1] = {key};
+    insert_key<1>(*pk, h, d);
+}
+
 constexpr int PART_ITER = 8;  // lists an octet serves per pass of the flush (256 lists per pass)
 __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
@@ -52,8 +78,6 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     unsigned long long *s_meta = s_lim + nb;
     uint32_t *s_tail = reinterpret_cast<uint32_t *>(s_meta + nb);
     uint32_t *s_head = s_tail + nb;
-    constexpr uint32_t OVF_N = 64;
-    constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
     __shared__ uint64_t s_ovk[OVF_N];   // spilled hot keys (xor OVF_SALT, 0 = free) and their counts
     __shared__ uint32_t s_ovc[OVF_N];
     const uint32_t tid = threadIdx.x;
@@ -71,25 +95,12 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     constexpr uint64_t BATCH_REC = (uint64_t)PART_NT * PART_RPT;
     const uint64_t stride = (uint64_t)cpr * BATCH_REC;
 
-    // A sub-list has room for ~1.8x its expected share; what does not fit is almost always
-    // a handful of hot keys (k-mers that occur once per read, thousands of times in all).
-    // They are folded into a small LDS cache and reach the table through ONE atomic insert
-    // per key and workgroup at the end, instead of one contended atomic per occurrence.
+    // TableParams is the first kernel argument: the slow paths read it from the argument segment
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t spilled = 0;  // per thread; one atomic per wave at the end
     auto spill = [&](uint64_t key) {
         ++spilled;
-        const uint64_t kk = key ^ OVF_SALT;
-        if (kk != 0) {
-            uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
-            for (int pr = 0; pr < 4; ++pr) {
-                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot]), 0ULL,
-                                                         (unsigned long long)kk);
-                if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
-                slot = (slot + 1) & (OVF_N - 1);
-            }
-        }
-        const uint64_t h[1] = {key};
-        insert_key<1>(p, h, 1);
+        part_spill(pk, key, s_ovk, s_ovc);
     };
     auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
         if (dbg & 256) return;  // ablation: no stores
@@ -160,15 +171,25 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             const uint64_t i = base + stride + (uint64_t)q * PART_NT + tid;
             nxt[q] = (i < n) ? in[i] : 0;
         }
+        // all ring places of the batch are taken before any is used: the eight returning LDS atomics
+        // of a thread are in flight together
+        uint32_t bq[PART_RPT], slot[PART_RPT], head[PART_RPT];
+#pragma unroll
+        for (int q = 0; q < PART_RPT; ++q) {
+            const uint64_t i = base + (uint64_t)q * PART_NT + tid;
+            bq[q] = (uint32_t)(cur[q] >> shift) & (nb - 1);
+            slot[q] = (i < n) ? atomicAdd(&s_tail[bq[q]], 1u) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < PART_RPT; ++q) head[q] = s_head[bq[q]];
 #pragma unroll
         for (int q = 0; q < PART_RPT; ++q) {
             const uint64_t i = base + (uint64_t)q * PART_NT + tid;
             if (i < n) {
                 const uint64_t key = cur[q];
-                const uint32_t b = (uint32_t)(key >> shift) & (nb - 1);
-                const uint32_t slot = atomicAdd(&s_tail[b], 1u);
-                if (slot - s_head[b] < CAP) {
-                    s_stage[((size_t)b << capbits) + (slot & cmask)] = key;
+                const uint32_t b = bq[q];
+                if (slot[q] - head[q] < CAP) {
+                    s_stage[((size_t)b << capbits) + (slot[q] & cmask)] = key;
                 } else {  // ring full: take the next place of the list directly
                     const unsigned long long at = atomicAdd(&s_cur[b], 1ULL);
                     put(key, at, s_lim[b]);
@@ -188,10 +209,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             const uint64_t li = ((uint64_t)r * nb + b) * cpr + c;
             dst_cnt[li] = min(s_cur[b], s_lim[b]) - li * dst_cap;
         }
-    if (tid < OVF_N && s_ovc[tid]) {
-        const uint64_t h[1] = {s_ovk[tid] ^ OVF_SALT};
-        insert_key<1>(p, h, s_ovc[tid]);
-    }
+    if (tid < OVF_N && s_ovc[tid]) part_insert(pk, s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
     for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
     if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
 }
