@@ -323,6 +323,41 @@ def test_edge_cases(T, name):
     assert_same_as_oracle(T, EDGE_TEXTS[name], 8, 12, 0)
 
 
+def _fuzz_text(rng):
+    """Random FASTQ-ish text: record pieces of any length (0 included), stray empty lines, CR before
+    LF, bytes outside ACGT, a missing final newline, a truncated last record."""
+    alpha = np.frombuffer(b"ACGTACGTACGTACGTNacgt", dtype=np.uint8)
+    out = []
+    for r in range(int(rng.integers(1, 60))):
+        n = int(rng.choice([0, 1, 5, 9, 15, 16, 17, 31, 32, 33, 47, 48, 64, 100, 257])) if rng.random() < 0.5 \
+            else int(rng.integers(0, 140))
+        if rng.random() < 0.15:
+            seq = bytes([int(rng.choice(alpha[:4]))]) * n          # homopolymer read
+        else:
+            seq = bytes(rng.choice(alpha, size=n))
+        eol = b"\r\n" if rng.random() < 0.05 else b"\n"
+        lines = [b"@" + b"h" * int(rng.integers(0, 40)), seq, b"+", b"I" * int(rng.integers(0, 140))]
+        for ln in lines:
+            if rng.random() < 0.1:
+                out.append(b"\n" * int(rng.integers(1, 3)))       # empty lines are dropped by the reader
+            out.append(ln + eol)
+    text = b"".join(out)
+    if rng.random() < 0.3:
+        text = text[:max(0, len(text) - int(rng.integers(1, 40)))]  # cut inside the last record
+    return text
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzzed_record_structure_both_paths(T, seed):
+    """Strips of 16 start positions, half-strips, tiles of 4 KiB and line ends fall everywhere in
+    these texts; both insert paths must agree with the oracle for a k drawn per seed."""
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.integers(8, 33))
+    text = b"".join(_fuzz_text(rng) for _ in range(int(rng.integers(1, 6))))
+    assert_same_as_oracle(T, text, k, 15, 0, path="partitioned")
+    assert_same_as_oracle(T, text, k, 15, 2, path="atomic", overflow_l=15)
+
+
 def test_long_reads_span_many_tiles(T):
     # one 50 kb read (the bundled fixture has 20 kb reads) + long header and quality lines
     rng = np.random.default_rng(3)
