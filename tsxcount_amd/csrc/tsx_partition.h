@@ -305,7 +305,16 @@ __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uin
         for (uint32_t b = tid; b < nb; b += PART_NT) s_h[b] = 0;
         lds_barrier();
         const uint64_t lo = min(n, (uint64_t)g * region_len), hi = min(n, lo + region_len);
-        for (uint64_t i = lo + tid; i < hi; i += PART_NT) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & (nb - 1)], 1u);
+        // four independent loads per thread and round: the kernel is a stream, not a latency chain
+        uint64_t i = lo + tid;
+        for (; i + 3 * PART_NT < hi; i += 4 * PART_NT) {
+            const uint64_t k0 = keys[i], k1 = keys[i + PART_NT], k2 = keys[i + 2 * PART_NT], k3 = keys[i + 3 * PART_NT];
+            atomicAdd(&s_h[(uint32_t)(k0 >> shift) & (nb - 1)], 1u);
+            atomicAdd(&s_h[(uint32_t)(k1 >> shift) & (nb - 1)], 1u);
+            atomicAdd(&s_h[(uint32_t)(k2 >> shift) & (nb - 1)], 1u);
+            atomicAdd(&s_h[(uint32_t)(k3 >> shift) & (nb - 1)], 1u);
+        }
+        for (; i < hi; i += PART_NT) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & (nb - 1)], 1u);
         lds_barrier();
         for (uint32_t b = tid; b < nb; b += PART_NT) hist[(size_t)b * G + g] = s_h[b];
         if (tid == 0) { region_start[g] = lo; region_cnt[g] = hi - lo; }
