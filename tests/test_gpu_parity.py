@@ -646,17 +646,18 @@ def test_two_rank_merge_on_one_gpu():
         assert "MERGE OK" in o
 
 
-def test_sharded_counting_on_one_gpu():
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_counting_on_one_gpu(world):
     """The multi-GPU counting pipeline (keys travel to the shard that owns their slot range,
-    then are built there) with 2 ranks on cuda:0 and a gloo all-to-all staged through host memory."""
+    then are built there) with 2 and 4 ranks on cuda:0 and a gloo all-to-all staged through host memory."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     script = os.path.join(ROOT, "tests", "_shard_worker.py")
-    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(port)], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o

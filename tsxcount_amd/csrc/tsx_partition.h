@@ -275,20 +275,26 @@ __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *sr
         lds_barrier();
         const uint64_t n = min((uint64_t)src_cnt[r], src_cap);
         const uint64_t *in = src + (uint64_t)r * src_cap;
+        // one returning LDS atomic per 64 keys, whatever the fan-out: lane d reserves the run of
+        // destination d; the next keys are already in flight while a row is placed
+        uint64_t nxt = (tid < n) ? in[tid] : 0;
         for (uint64_t base = 0; base < n; base += PART_NT) {
             const uint64_t i = base + tid;
             const bool have = i < n;
-            const uint64_t key = have ? in[i] : 0;
+            const uint64_t key = nxt;
+            nxt = (i + PART_NT < n) ? in[i + PART_NT] : 0;
             const uint32_t o = have ? ((uint32_t)(key >> shift) & (nown - 1)) : 0xFFFFFFFFu;
+            unsigned long long my_mk = 0;
+            uint32_t cnt_d = 0;
             for (uint32_t d = 0; d < nown; ++d) {
                 const unsigned long long mk = __ballot(o == d);
-                if (mk == 0ULL) continue;
-                unsigned long long at = 0;
-                if (lane == (uint32_t)__builtin_ctzll(mk))
-                    at = atomicAdd(&s_cur[d], (unsigned long long)__builtin_popcountll(mk));
-                at = __shfl(at, __builtin_ctzll(mk), 64);
-                if (o == d) dst[at + __builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = key;
+                if (o == d) my_mk = mk;
+                if (lane == d) cnt_d = (uint32_t)__builtin_popcountll(mk);
             }
+            unsigned long long at = 0;
+            if (lane < nown && cnt_d) at = atomicAdd(&s_cur[lane], (unsigned long long)cnt_d);
+            at = __shfl(at, (int)(o & 63u), 64);
+            if (have) dst[at + __builtin_popcountll(my_mk & ((1ULL << lane) - 1ULL))] = key;
         }
     }
 }
