@@ -84,9 +84,10 @@ int tsx_hip_decode(const uint64_t *limbs, int k, char *out);
  *                TSXHashMapPerf.h:699-881).
  *   overflow_l   log2 slots of the secondary array; 0 = max(10, l-4).
  *   hash_seed    seed of the bijective GF(2) mapping; the reference draws it
- *                from time(NULL) (BijectiveKMapping.h:84).  The matrix is L*U of two
- *                random unit triangular matrices (the reference uses U alone, which
- *                makes the slot a function of the first l/2 bases only).
+ *                from time(NULL) (BijectiveKMapping.h:84).  The matrix is dense:
+ *                multiplication by a random element of GF(2^2k) for k <= 32, L*U of
+ *                two random unit triangular matrices above (the reference uses U
+ *                alone, which makes the slot a function of the first l/2 bases only).
  *   device       HIP device ordinal.
  */
 int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,

@@ -140,8 +140,9 @@ def test_other_hash_seeds_give_the_same_counts(T):
 def test_mapping_is_bijective_linear_and_mixes_all_bits(T):
     """IBijectiveFunction contract (IBijectiveFunction.h:26-27): apply/inv_apply are inverse,
     GF(2)-linear.  Unlike the reference's unit upper triangular matrix (the oracle's family:
-    output bit p ignores input bits above p) the product's L*U matrix lets the top key bits
-    reach the slot index, so k-mers that share a prefix do not share a home slot."""
+    output bit p ignores input bits above p) the product's dense matrix (multiplication in
+    GF(2^2k) for k <= 32, L*U above) lets the top key bits reach the slot index, so k-mers that
+    share a prefix do not share a home slot."""
     from oracle.oracle import Oracle
     for k in (14, 31, 63, 127):
         m = T.TSXHashMapHIP(12, 0, k, hash_seed=5)

@@ -128,8 +128,8 @@ extern "C" int tsx_hip_decode(const uint64_t *limbs, int k, char *out) {
 // that share a 15-base prefix share one home slot AND one probe sequence.  The
 // reference survives that with up to 2^l reprobes; an 8-bit reprobe field does not
 // (AT-rich reads at load 0.48 already exhausted 255 probes, scripts/skew_check.py).
-// So the matrix here is M = L * U with U drawn exactly like the reference's matrix and
-// L a unit LOWER triangular matrix from the same generator: still bijective and
+// So the matrix here is not triangular (make_mapping() below: multiplication by a random
+// field element for one-limb keys, L * U for longer ones): still bijective and
 // GF(2)-linear (same IBijectiveFunction contract, same LUT evaluation), but every
 // key bit reaches the slot index.  Counts do not depend on the matrix.  Seeded
 // splitmix64 replaces srand(time(NULL)).
