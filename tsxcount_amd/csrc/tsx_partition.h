@@ -64,13 +64,13 @@ __device__ __attribute__((noinline)) void part_insert(const TableParams *pk, uin
     insert_key<1>(*pk, h, d);
 }
 
-constexpr int PART_ITER = 8;  // lists an octet serves per pass of the flush (256 lists per pass)
+constexpr int PART_ITER = 4;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
 __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg) {
-    extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads
+    extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
     unsigned long long *s_cur = reinterpret_cast<unsigned long long *>(s_part + ((size_t)nb << capbits));
@@ -78,12 +78,15 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     unsigned long long *s_meta = s_lim + nb;
     uint32_t *s_tail = reinterpret_cast<uint32_t *>(s_meta + nb);
     uint32_t *s_head = s_tail + nb;
+    uint32_t *s_job = s_head + nb;      // lists with something to flush this round, in arrival order
+    __shared__ uint32_t s_njobs[2];     // their number; two counters used alternately (reset one round ahead)
     __shared__ uint64_t s_ovk[OVF_N];   // spilled hot keys (xor OVF_SALT, 0 = free) and their counts
     __shared__ uint32_t s_ovc[OVF_N];
     const uint32_t tid = threadIdx.x;
     const uint32_t r = blockIdx.x / cpr, c = blockIdx.x % cpr;
     if (r >= nregions) return;
     if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
+    if (tid < 2) s_njobs[tid] = 0;
     for (uint32_t b = tid; b < nb; b += PART_NT) {
         s_tail[b] = 0; s_head[b] = 0;
         if (offs) { s_cur[b] = offs_base[b] + offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
@@ -107,7 +110,11 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         if (at < lim) dst[at] = key;
         else spill(key);  // sub-list full
     };
+    uint32_t round = 0;   // flush rounds so far (workgroup-uniform)
     auto flush = [&](bool all) {
+        const uint32_t par = round & 1u;
+        ++round;
+        if (tid == 0) s_njobs[par ^ 1u] = 0;   // next round's counter: nobody reads or writes it in this round
         for (uint32_t b = tid; b < nb; b += PART_NT) {  // (A)
             const uint32_t head = s_head[b];
             const uint32_t tail = min(s_tail[b], head + CAP);  // arrivals past the ring went out directly
@@ -121,24 +128,31 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             s_head[b] = head + nout;
             s_tail[b] = tail;
             s_cur[b] = at + nout;
+            if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;   // about half of the lists in a usual round
         }
         lds_barrier();
-        const uint32_t oct = tid >> 3, ol = tid & 7;  // (B)
+        const uint32_t oct = tid >> 3, ol = tid & 7;  // (B): an octet of lanes per job
         if (dbg & 512) return;  // ablation: bookkeeping only
-        for (uint32_t g0 = 0; g0 < nb; g0 += PART_ITER * (PART_NT / 8)) {
+        const uint32_t njobs = s_njobs[par];
+        for (uint32_t j0 = 0; j0 < njobs; j0 += PART_ITER * (PART_NT / 8)) {
             unsigned long long meta[PART_ITER], lim[PART_ITER];
+            uint32_t bj[PART_ITER];
             uint64_t k0[PART_ITER], k1[PART_ITER];
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t b = g0 + oct + u * (PART_NT / 8);
-                meta[u] = (b < nb) ? s_meta[b] : 0ULL;
-                lim[u] = (b < nb) ? s_lim[b] : 0ULL;
+                const uint32_t j = j0 + oct + u * (PART_NT / 8);
+                bj[u] = (j < njobs) ? s_job[j] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t b = g0 + oct + u * (PART_NT / 8);
+                const uint32_t j = j0 + oct + u * (PART_NT / 8);
+                meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
+                lim[u] = (j < njobs) ? s_lim[bj[u]] : 0ULL;
+            }
+#pragma unroll
+            for (int u = 0; u < PART_ITER; ++u) {
                 const uint32_t nout = (uint32_t)(meta[u] & 0xFF), hd = (uint32_t)(meta[u] >> 8) & 0xFF;
-                const uint64_t *ring = s_stage + ((size_t)b << capbits);
+                const uint64_t *ring = s_stage + ((size_t)bj[u] << capbits);
                 k0[u] = (ol < nout) ? ring[(hd + ol) & cmask] : 0;
                 k1[u] = (ol + 8 < nout) ? ring[(hd + ol + 8) & cmask] : 0;
             }
@@ -149,9 +163,8 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
                 if (ol < nout) put(k0[u], at + ol, lim[u]);
                 if (ol + 8 < nout) put(k1[u], at + ol + 8, lim[u]);
                 if (nout > 16) {  // only rings deeper than 16 or the final flush get here
-                    const uint32_t b = g0 + oct + u * (PART_NT / 8);
                     const uint32_t hd = (uint32_t)(meta[u] >> 8) & 0xFF;
-                    const uint64_t *ring = s_stage + ((size_t)b << capbits);
+                    const uint64_t *ring = s_stage + ((size_t)bj[u] << capbits);
                     for (uint32_t q = ol + 16; q < nout; q += 8) put(ring[(hd + q) & cmask], at + q, lim[u]);
                 }
             }

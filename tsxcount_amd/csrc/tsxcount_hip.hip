@@ -559,7 +559,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         while ((1u << bits) < PART_FLUSH + 2 * mean && bits < 6) ++bits;
         return bits;
     };
-    auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 32); };
+    auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 36); };
     hipLaunchKernelGGL(offsets_rows_kernel, dim3(pl.nb1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs,
                        (uint32_t)pl.g, pl.c_bcnt);
     hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, pl.nb1, pl.c_bstart, pl.c_bcnt);
