@@ -2,7 +2,9 @@
 //
 //   line_count_kernel   FASTQ pass 1: non-empty line terminators per tile
 //   line_*scan* kernels FASTQ pass 2: exclusive scan -> line index at tile start
-//   count_fastq_kernel  FASTQ pass 3: scan + 2-bit encode + hash + dedup + insert
+//   count_fastq_kernel  FASTQ pass 3, atomic path: scan + 2-bit encode + hash + dedup + insert
+//   scan_log_kernel     FASTQ pass 3, partitioned path (k <= 32): strips of 16 positions per
+//                       lane, rolling hash, per-wave key log (tsx_partition.h takes it from there)
 //   add_kmers_kernel    addKmer for a batch of encoded k-mers
 //   get_counts_kernel   getKmerCount(kmer) for a batch
 //   occupied_kernel     getKmerCount() (occupied slots)
