@@ -45,7 +45,8 @@ constexpr int PART_FLUSH = 16;   // keys per burst (128 B = one L2 line)
 // insert_key() would otherwise be inlined at every store of the flush and serialise the scatter.
 constexpr uint32_t OVF_N = 64;
 constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
-__device__ __attribute__((noinline)) void part_spill(const TableParams *pk, uint64_t key, uint64_t *ovk, uint32_t *ovc) {
+__device__ __attribute__((noinline)) void part_spill(const TableParams *pk, uint64_t key, uint64_t *ovk, uint32_t *ovc,
+                                                     uint64_t *ovq, uint32_t *ovn, uint32_t ovq_cap) {
     const uint64_t kk = key ^ OVF_SALT;
     if (kk != 0) {
         uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
@@ -55,6 +56,14 @@ __device__ __attribute__((noinline)) void part_spill(const TableParams *pk, uint
             if (old == 0ULL || old == kk) { atomicAdd(&ovc[slot], 1u); return; }
             slot = (slot + 1) & (OVF_N - 1);
         }
+    }
+    // Not a cached hot key: an ordinary key that found its list filled up by one.  It goes to this
+    // workgroup's overflow queue (plain store; overflow_insert_kernel inserts the queues afterwards, all
+    // lanes of the chip at once).  Inserting right here cost 1.7 ms: a dependent global CAS per key, one
+    // workgroup after all others had finished.
+    if (ovq) {
+        const uint32_t at = atomicAdd(ovn, 1u);
+        if (at < ovq_cap) { ovq[at] = key; return; }
     }
     const uint64_t h[1] = {key};
     insert_key<1>(*pk, h, 1);
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
-    uint32_t capbits, int dbg) {
+    uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap) {
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     uint32_t *s_head = s_tail + nb;
     uint32_t *s_job = s_head + nb;      // lists with something to flush this round, in arrival order
     __shared__ uint32_t s_njobs[2];     // their number; two counters used alternately (reset one round ahead)
+    __shared__ uint32_t s_ovn;          // keys in this workgroup's overflow queue
     __shared__ uint64_t s_ovk[OVF_N];   // spilled hot keys (xor OVF_SALT, 0 = free) and their counts
     __shared__ uint32_t s_ovc[OVF_N];
     const uint32_t tid = threadIdx.x;
@@ -87,6 +97,8 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     if (r >= nregions) return;
     if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
     if (tid < 2) s_njobs[tid] = 0;
+    if (tid == 0) s_ovn = 0;
+    uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
     for (uint32_t b = tid; b < nb; b += PART_NT) {
         s_tail[b] = 0; s_head[b] = 0;
         if (offs) { s_cur[b] = offs_base[b] + offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     uint32_t spilled = 0;  // per thread; one atomic per wave at the end
     auto spill = [&](uint64_t key) {
         ++spilled;
-        part_spill(pk, key, s_ovk, s_ovc);
+        part_spill(pk, key, s_ovk, s_ovc, ovq, &s_ovn, ovq_cap);
     };
     auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
         if (dbg & 256) return;  // ablation: no stores
@@ -223,8 +235,21 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             dst_cnt[li] = min(s_cur[b], s_lim[b]) - li * dst_cap;
         }
     if (tid < OVF_N && s_ovc[tid]) part_insert(pk, s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
+    if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
     for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
     if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
+}
+
+// Inserts the overflow queues partition_ring_kernel left behind (one queue of `cap` places per workgroup).
+__global__ __launch_bounds__(PART_NT) void overflow_insert_kernel(TableParams p, const uint64_t *ovq_all,
+                                                                  const uint32_t *ovq_cnt, uint32_t cap, uint32_t nq) {
+    for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+        const uint32_t n = ovq_cnt[qi];
+        for (uint32_t i = threadIdx.x; i < n; i += PART_NT) {
+            const uint64_t h[1] = {ovq_all[(size_t)qi * cap + i]};
+            insert_key<1>(p, h, 1);
+        }
+    }
 }
 
 // Write offsets from the level-1 histograms hist[b * G + g] (bucket-major), two steps:

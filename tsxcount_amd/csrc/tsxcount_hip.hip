@@ -35,6 +35,7 @@ static int scan_wg_per_cu() {  // scan_log_kernel workgroups per CU: 4 are resid
     return v;
 }
 #define SCAN_WG_PER_CU scan_wg_per_cu()
+static const uint32_t OVQ_CAP = 2048;  // keys per overflow queue (one queue per level-2 workgroup: 32 MiB at 2048 workgroups)
 static const size_t STAGE_PIECE_DEFAULT = (size_t)64 << 20;  // bytes of FASTQ per host piece
 
 struct tsx_hip_map {
@@ -47,6 +48,9 @@ struct tsx_hip_map {
     std::vector<uint64_t> rows, irows;   // n x wk
     std::vector<uint64_t> lut, ilut;     // [groups][1<<g][wk]
     uint64_t *d_lut = nullptr, *d_ilut = nullptr, *d_roll = nullptr;
+    uint64_t *d_ovq = nullptr;           // overflow queues of the level-2 partition (OVQ_CAP keys per workgroup)
+    uint32_t *d_ovq_cnt = nullptr;
+    size_t ovq_queues = 0;
     uint64_t roll[64] = {0};             // one-limb keys: sliding-window hash update table
     // FASTQ scratch
     uint32_t *d_tile = nullptr; uint64_t tile_cap = 0;
@@ -397,6 +401,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
+    (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt);
     (void)hipFree(m->d_tile); (void)hipFree(m->d_carry); (void)hipFree(m->d_seg);
     (void)hipFree(m->p.seg_dirty); (void)hipFree(m->d_buf[0]); (void)hipFree(m->d_buf[1]); (void)hipFree(m->d_cnt);
     for (int i = 0; i < 2; ++i) {
@@ -568,7 +573,8 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st, m->p, src,
                            region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u, m->d_buf[1],
                            (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
-                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg);
+                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
+                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u);
         HIP_TRY(hipGetLastError());
     }
     if (ev) HIP_TRY(hipEventRecord(ev[4], st));
@@ -578,11 +584,25 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     uint32_t pieces = 1;
     if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
         const uint32_t bits = ring_bits(pl.nb2);
+        const uint32_t nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup
+        if ((size_t)nq2 > m->ovq_queues) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (m->d_ovq) HIP_TRY(hipFree(m->d_ovq));
+            if (m->d_ovq_cnt) HIP_TRY(hipFree(m->d_ovq_cnt));
+            m->d_ovq = nullptr; m->d_ovq_cnt = nullptr; m->ovq_queues = 0;
+            HIP_TRY(hipMalloc((void **)&m->d_ovq, (size_t)nq2 * OVQ_CAP * 8));
+            HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, (size_t)nq2 * 4));
+            m->ovq_queues = nq2;
+        }
         hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.nb1 * pl.cpr2), dim3(PART_NT), part_lds(pl.nb2, bits), st, m->p,
                            (const uint64_t *)m->d_buf[1], (const unsigned long long *)pl.c_bstart,
                            (const unsigned long long *)pl.c_bcnt, (uint64_t)0, pl.nb1, pl.cpr2, m->d_buf[0],
                            (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, pl.c_seg,
-                           pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg);
+                           pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg, m->d_ovq, m->d_ovq_cnt, OVQ_CAP);
+        HIP_TRY(hipGetLastError());
+        // ordinary keys that found their sub-list filled up by a hot key: inserted now, by the whole chip
+        hipLaunchKernelGGL(overflow_insert_kernel, dim3(std::min<uint32_t>(nq2, (uint32_t)m->cus * 8)), dim3(PART_NT), 0, st,
+                           m->p, (const uint64_t *)m->d_ovq, (const uint32_t *)m->d_ovq_cnt, OVQ_CAP, nq2);
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
