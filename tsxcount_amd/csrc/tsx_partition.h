@@ -113,8 +113,21 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     // TableParams is the first kernel argument: the slow paths read it from the argument segment
     const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t spilled = 0;  // per thread; one atomic per wave at the end
+    // In line: one probe of the spill cache (a cached hot key hits it) and the overflow queue (an
+    // ordinary key misses).  A call here makes the wave wait for every store it has in flight.
     auto spill = [&](uint64_t key) {
         ++spilled;
+        const uint64_t kk = key ^ OVF_SALT;
+        if (kk != 0) {
+            const uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot]), 0ULL,
+                                                     (unsigned long long)kk);
+            if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
+        }
+        if (ovq) {
+            const uint32_t at = atomicAdd(&s_ovn, 1u);
+            if (at < ovq_cap) { ovq[at] = key; return; }
+        }
         part_spill(pk, key, s_ovk, s_ovc, ovq, &s_ovn, ovq_cap);
     };
     auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
