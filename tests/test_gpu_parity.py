@@ -258,6 +258,28 @@ def test_log_region_overflow_takes_the_side_path(T, monkeypatch):
     monkeypatch.delenv("TSX_HIP_LOG_CAP")
 
 
+def test_hot_keys_overflow_sub_lists_two_radix_levels(T):
+    """Every read ends in the same 40 bases: the 10 k-mers inside that suffix occur once per read.  At
+    l = 23 the table is split by two radix levels; the hot keys fill their sub-lists, go through the
+    level-2 spill cache, and the ordinary keys they displace go through the overflow queues.  Every
+    count must still be exact."""
+    rng = np.random.default_rng(77)
+    n_reads, body, k = 30000, 90, 31
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    suffix = lut[rng.integers(0, 4, 40)].tobytes()
+    bodies = lut[rng.integers(0, 4, (n_reads, body))]
+    qual = b"I" * (body + 40)
+    text = b"".join(b"@r%d\n" % i + bodies[i].tobytes() + suffix + b"\n+\n" + qual + b"\n" for i in range(n_reads))
+    st = assert_same_as_oracle(T, text, k, 23, 0, path="partitioned")
+    assert st["fallback_inserts"] > 10 * n_reads // 2   # the spill path really ran
+    m = T.TSXHashMapHIP(23, 0, k)
+    m.set_path("partitioned")
+    m.countFastq(text)
+    hot = T.encode_many([suffix[i:i + k] for i in range(10)], k)
+    assert (m.getKmerCounts(hot) == n_reads).all()
+    m.close()
+
+
 def test_stage_timing_hooks(T):
     from tsxcount_amd import synth
     text = synth.fastq(5, 0, 3000)
