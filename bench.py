@@ -21,57 +21,126 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(k, seed, max_seconds=60):
+def cpu_baseline(k, seed, max_seconds=90):
     """Time the real reference (oracle/_ref/tsxCount_ref, --mode=CAS) on a bounded
     sample of the same synthetic reads, on this box's host cores.
 
-    The reference's CAS mode is not robust under threads (unsynchronised
-    std::set inserts and retry loops: it live-locks at 16 threads on this input and
-    sometimes crashes at 8), so thread counts are tried from 8 downwards and the
-    first run that exits 0 is reported, with the failed attempts listed."""
+    What is reported: k-mers of the sample / (wall time of the run - wall time of the same
+    binary on an EMPTY input), i.e. process start-up, option parsing, the random-matrix
+    set-up and the allocation of the 2^23-slot table are measured and subtracted (they
+    are ~10 ms of a 10-15 s run).  `cores` = the OpenMP threads the run used,
+    `host_cores` = os.cpu_count() of the box.  The reference's CAS mode is not robust under
+    threads (unsynchronised std::set inserts and retry loops: it live-locks at 16 threads
+    on this input and sometimes crashes at 8), so thread counts are tried from 8 downwards
+    and the first run that exits 0 is reported, with the failed attempts listed."""
     from tsxcount_amd import synth
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "tsxCount_ref")
     attempts = []
+    host_cores = os.cpu_count() or 1
+
+    def run_ref(td, text, threads):
+        path = os.path.join(td, "sample.fastq")
+        with open(path, "wb") as f:
+            f.write(text)
+        # 2k+s must be a multiple of 8 for the reference's byte-wise CAS
+        # stores to stay aligned (TSXHashMapCAS.h:141-232): k=31 -> s=2.
+        cmd = [ref_bin, "--input=" + path, "--k=%d" % k, "--l=23", "--s=%d" % ((-2 * k) % 8 or 8), "--mode=CAS",
+               "--threads=%d" % threads]
+        t0 = time.time()
+        try:
+            rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                timeout=max_seconds).returncode
+        except subprocess.TimeoutExpired:
+            rc = "timeout"
+        return rc, time.time() - t0
+
     if os.path.exists(ref_bin):
         for threads, n_reads in ((8, 3000), (8, 3000), (4, 1500), (2, 800), (1, 400)):
-            threads = max(1, min(threads, os.cpu_count() or 1))
+            threads = max(1, min(threads, host_cores))
             text = synth.fastq(seed, 0, n_reads)
             nrand, na = synth.read_lengths(seed, 0, n_reads)
             kmers = int(((nrand + na) - k + 1).clip(min=0).sum())
             with tempfile.TemporaryDirectory() as td:
-                path = os.path.join(td, "sample.fastq")
-                with open(path, "wb") as f:
-                    f.write(text)
-                # 2k+s must be a multiple of 8 for the reference's byte-wise CAS
-                # stores to stay aligned (TSXHashMapCAS.h:141-232): k=31 -> s=2.
-                cmd = [ref_bin, "--input=" + path, "--k=%d" % k, "--l=23", "--s=2", "--mode=CAS",
-                       "--threads=%d" % threads]
-                t0 = time.time()
-                try:
-                    rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                        timeout=max_seconds).returncode
-                except subprocess.TimeoutExpired:
-                    rc = "timeout"
-                dt = time.time() - t0
-            if rc == 0:
-                return {"value": kmers / dt, "unit": "k-mers/s", "cores": threads, "kind": "reference",
-                        "sample": "%d synthetic reads (%d k-mers), k=%d, tsxCount --mode=CAS --l=23 --s=2 "
-                                  "--threads=%d, wall time of the whole run" % (n_reads, kmers, k, threads),
+                rc0, dt0 = run_ref(td, b"", threads)
+                rc, dt = run_ref(td, text, threads)
+            if rc == 0 and rc0 == 0 and dt > dt0:
+                return {"value": kmers / (dt - dt0), "unit": "k-mers/s", "cores": threads, "host_cores": host_cores,
+                        "kind": "reference", "seconds": round(dt, 2), "startup_seconds_subtracted": round(dt0, 3),
+                        "sample": "%d synthetic reads (%d k-mers), k=%d, tsxCount --mode=CAS --l=23 --s=%d "
+                                  "--threads=%d; wall time minus the wall time of an empty-input run"
+                                  % (n_reads, kmers, k, (-2 * k) % 8 or 8, threads),
                         "failed_attempts": attempts}
             attempts.append({"threads": threads, "reads": n_reads, "rc": rc, "seconds": round(dt, 1)})
     # fall back to the C restatement (single core)
     from oracle.oracle import Oracle
-    n_reads = 3000
+    n_reads = 12000
     text = synth.fastq(seed, 0, n_reads)
     nrand, na = synth.read_lengths(seed, 0, n_reads)
     kmers = int(((nrand + na) - k + 1).clip(min=0).sum())
-    o = Oracle(k, 23, 2, seed=1)
+    o = Oracle(k, 25, 2, seed=1)
     t0 = time.time()
     o.count_fastq(text)
     dt = time.time() - t0
-    return {"value": kmers / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic reads (%d k-mers), k=%d, oracle/tsx_oracle.c serial" % (n_reads, kmers, k),
+    return {"value": kmers / dt, "unit": "k-mers/s", "cores": 1, "host_cores": host_cores, "kind": "port",
+            "seconds": round(dt, 2),
+            "sample": "%d synthetic reads (%d k-mers), k=%d, oracle/tsx_oracle.c serial, in-process "
+                      "(count phase only)" % (n_reads, kmers, k),
             "failed_attempts": attempts}
+
+
+def run_check(args, m, T, TD, dist, torch, dist_on, sharded, world, rank, red, dev, local_rank, text, nbytes,
+              kmers_rank, kmers_total, first):
+    """The --check of the synthetic workload, outside the timed region (tsxcount_amd/verify.py):
+    totals read back from the table, the analytic polyA count, exact lookups of a sample of
+    reads, and (one GPU) a second table filled through the other insert path."""
+    from tsxcount_amd import verify
+    detail = {}
+    st = m.stats()
+    ok = st["insert_failures"] == 0 and st["overflow_failures"] == 0 and st["lock_timeouts"] == 0
+    detail["failure_counters"] = {k2: st[k2] for k2 in ("insert_failures", "overflow_failures", "lock_timeouts")}
+
+    def allsum(v):
+        if not dist_on:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=red)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    # totals: every k-mer of the reads was scanned, and the counts held by the table(s) add up to them
+    scanned = allsum(st["kmers_added"]) if (world == 1 or sharded) else None
+    count_sum = allsum(st["count_sum"])
+    detail["totals"] = {"kmers_in_reads": kmers_total, "scanned": scanned, "sum_of_counts_in_table": count_sum}
+    ok = ok and count_sum == kmers_total and (scanned is None or scanned == kmers_total)
+    # polyA: analytic count from the generator (all ranks' reads) vs the table (its owner answers)
+    _, _, npolya = T.synth_sizes(args.seed, first, args.reads, args.k, want_polya=True)
+    polya_expect = allsum(npolya)
+    polya_got = allsum(m.getKmerCount("A" * args.k))
+    detail["polyA"] = {"expected": polya_expect, "table": polya_got}
+    ok = ok and polya_got == polya_expect
+    # sample of rank 0's reads, looked up on every rank (non-owners answer 0), summed
+    ids = verify.sample_read_ids(0, args.reads, args.check_reads)
+    kmers, mult, safe = verify.sample_expectations(args.seed, args.k, ids)
+    got = m.getKmerCounts(kmers)
+    if dist_on:
+        g = torch.from_numpy(got.astype("int64")).to(red)
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        got = g.cpu().numpy().astype("uint64")
+    detail["sample"] = dict(verify.judge_sample(got, mult, safe), reads=int(len(ids)))
+    ok = ok and detail["sample"]["below_sample_multiplicity"] == 0 and detail["sample"]["safe_unequal"] == 0 \
+        and detail["sample"]["looked_up"] > 0
+    # second table through the other insert path (single table only)
+    if not dist_on and not args.no_cross_check:
+        other = "partitioned" if args.path == "atomic" else "atomic"
+        detail["cross"] = verify.cross_check(m, text.data_ptr(), nbytes, other, device=local_rank)
+        ok = ok and detail["cross"]["ok"]
+    if dist_on:
+        # every distinct k-mer lives on exactly one rank
+        detail["distinct_total"] = allsum(st["distinct"])
+        ok = ok and 0 < detail["distinct_total"] <= kmers_total
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(int(okt.item()))
+    return ok, detail
 
 
 def main():
@@ -89,10 +158,24 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo only to rehearse N > 1 on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-reads", type=int, default=1000, help="reads whose k-mers the check looks up one by one")
+    ap.add_argument("--no-cross-check", action="store_true",
+                    help="skip the second table (other insert path) of the check")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded table, collectives) even at world size 1: "
                          "the only way to push the RCCL leg through its API on a 1-GPU box")
     args = ap.parse_args()
+
+    # One process per GPU: the launcher (python -m torch.distributed.run) sets WORLD_SIZE.  A bare
+    # `python bench.py --gpus 8` would silently measure one GPU, so it is refused -- before torch
+    # or the GPU is touched.
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != env_world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d. Launch one rank per GPU:\n"
+                         "  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                         "--master-port 29671 bench.py --gpus %d --steps %d --warmup %d\n"
+                         % (args.gpus, env_world, args.gpus, args.gpus, args.steps, args.warmup))
+        raise SystemExit(2)
 
     import torch
     import torch.distributed as dist
@@ -187,15 +270,8 @@ def main():
         kmers_total = kmers_rank
 
     st = m.stats()
-    check_ok = (st["insert_failures"] == 0 and st["overflow_failures"] == 0 and st["lock_timeouts"] == 0)
-    if world == 1 or sharded:
-        check_ok = check_ok and st["kmers_added"] == kmers_rank  # every k-mer of this rank's reads was scanned
-    if dist_on:
-        # every distinct k-mer ends up on exactly one rank; their number is the same whichever way the
-        # reads were spread, and (almost) every non-polyA k-mer of this generator is unique
-        dsum = torch.tensor([st["distinct"]], dtype=torch.int64, device=red)
-        dist.all_reduce(dsum, op=dist.ReduceOp.SUM)
-        check_ok = check_ok and 0.75 * kmers_total < int(dsum.item()) < kmers_total
+    check_ok, check_detail = run_check(args, m, T, TD, dist, torch, dist_on, sharded, world, rank, red, dev, local_rank,
+                                       text, nbytes, kmers_rank, kmers_total, first)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -248,7 +324,8 @@ def main():
                                       (", table sharded by slot range, keys exchanged by one RCCL all-to-all" if sharded
                                        else ", per-GPU tables merged over RCCL all-to-all") if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
-                       "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL"},
+                       "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL",
+                       "check_detail": check_detail},
             "roofline": {"bound": "hbm", "kernel": names[dom],
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

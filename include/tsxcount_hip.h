@@ -33,7 +33,8 @@ enum {
     TSX_HIP_EHIP = -4,      /* a HIP runtime call failed (see tsx_hip_last_error) */
     TSX_HIP_EFULL = -5,     /* a k-mer could not be placed: reference exit(42), TSXHashMap.h:340-343 */
     TSX_HIP_EOVERFLOW = -6, /* the secondary (count overflow) array is full */
-    TSX_HIP_ERANGE = -7     /* output buffer too small */
+    TSX_HIP_ERANGE = -7,    /* output buffer too small */
+    TSX_HIP_ELOCK = -8      /* a multi-limb slot stayed locked past the spin bound: counts may be wrong */
 };
 
 /* Layout the library derived from (k, l, storagebits); see DESIGN.md. */
@@ -62,6 +63,9 @@ typedef struct tsx_hip_stats {
     uint64_t overflow_used;    /* occupied secondary slots */
     uint64_t lock_timeouts;    /* multi-limb claim spins that gave up (must be 0) */
     uint64_t fallback_inserts; /* keys the partitioned path inserted atomically because a list was full */
+    uint64_t count_sum;        /* sum of getKmerCount(kmer) over every stored k-mer, read back from the slots
+                                  and the secondary array: equals kmers_added when nothing was lost (the
+                                  reference's --check walks every k-mer instead, main.cpp:224-396) */
 } tsx_hip_stats;
 
 int tsx_hip_key_limbs(int k);
@@ -106,7 +110,7 @@ int tsx_hip_get_layout(const tsx_hip_map *m, tsx_hip_layout *out);
 /* Zero the table, the secondary array and the counters. */
 int tsx_hip_clear(tsx_hip_map *m);
 /* Wait for everything queued on the map's stream and report sticky errors
- * (TSX_HIP_EFULL / TSX_HIP_EOVERFLOW) raised by earlier inserts.            */
+ * (TSX_HIP_EFULL / TSX_HIP_EOVERFLOW / TSX_HIP_ELOCK) raised by earlier inserts. */
 int tsx_hip_sync(tsx_hip_map *m);
 
 /*
@@ -115,6 +119,9 @@ int tsx_hip_sync(tsx_hip_map *m);
  * fromSequence + addKmer, for one whole FASTQ text.  Empty lines are skipped,
  * every 4 remaining lines are a record, line 2 is the sequence, every window
  * of k bytes of it is one k-mer.
+ *
+ * Both refuse a map created with shard_bits > 0 (TSX_HIP_EINVAL): a sharded table
+ * is filled through tsx_hip_shard_scan_device / tsx_hip_shard_build_device.
  *
  * _host copies `n` bytes from host memory through pinned staging buffers.
  * _device takes a device pointer (16-byte aligned, text starts at a record
@@ -189,6 +196,13 @@ int tsx_hip_dump_device(tsx_hip_map *m, void *dev_kmers_out, void *dev_counts_ou
  */
 int tsx_hip_partition_device(tsx_hip_map *m, int nranks, void *dev_kmers_out, void *dev_counts_out,
                              size_t cap, void *dev_seg_counts, void *stream);
+/*
+ * getAllKmers restricted to the table slots [slot_lo, slot_hi): a sample of the table for
+ * cross-checks at sizes where the whole dump would not fit (bench.py's check).  cap must be
+ * >= the number of occupied slots in the range (slot_hi - slot_lo always suffices).
+ */
+int tsx_hip_dump_range_device(tsx_hip_map *m, uint64_t slot_lo, uint64_t slot_hi, void *dev_kmers_out,
+                              void *dev_counts_out, size_t cap, void *dev_n, void *stream);
 int tsx_hip_owner_host(const tsx_hip_map *m, const uint64_t *kmer, int nranks);
 
 /* IBijectiveFunction::apply / inv_apply (IBijectiveFunction.h:26-27) on the host,
@@ -201,22 +215,36 @@ int tsx_hip_hash_rows(const tsx_hip_map *m, uint64_t *rows_out /* 2k x key_limbs
  * Multi-GPU counting with a sharded table (k <= 32).  Reads shard across the GPUs;
  * what travels between them is hashed keys BEFORE they are built into a table, not
  * table slots afterwards:
- *   shard_scan_device   scans this GPU's reads and writes the hashed keys of all
- *                       k-mers, grouped by owner GPU, into dev_send (capacity from
- *                       tsx_hip_shard_send_capacity); dev_send_counts[o] = keys for
- *                       owner o.  Keys that carry a count (hot k-mers merged on chip)
- *                       go to the (dev_hot_keys, dev_hot_counts) list, *dev_hot_n of them.
+ *   shard_scan_window_device  scans the window [win_off, win_off + win_len) of this GPU's
+ *                       device text (n_total bytes; win_off a multiple of 16; windows of one
+ *                       text are given in order, win_off == 0 restarts the line count, a
+ *                       window may begin anywhere -- inside a line, inside a record) and writes
+ *                       the hashed keys of all its k-mers grouped by owner GPU into dev_send
+ *                       (capacity from tsx_hip_shard_send_capacity(win_len)):
+ *                       dev_send_counts[o] = keys for owner o.  With dev_own != NULL the keys
+ *                       this GPU owns go there instead (they never travel) and dev_send holds
+ *                       the other owners' groups back to back.  Keys that carry a count (hot
+ *                       k-mers merged on chip) go to the (dev_hot_keys, dev_hot_counts) list,
+ *                       *dev_hot_n of them.  *dev_key_sum (optional) += sum of all keys
+ *                       written (mod 2^64): the integrity check of the exchange.
+ *   shard_scan_device   the same for a whole text as one window, own keys inside dev_send.
  *   -- all-to-all of the owner groups (RCCL), all-gather of the hot lists --
- *   shard_build_device  builds the received keys into this GPU's slot range
- *                       (radix partition + LDS segment build);
+ *   shard_build_device  builds the received keys into this GPU's slot range (radix
+ *                       partition + LDS segment build); *dev_key_sum (optional) += their sum.
  *   add_hashed_device   adds (hashed key, count) pairs, skipping other owners' keys.
- * tsxcount_amd/distributed.py: count_fastq_sharded().
+ * tsxcount_amd/distributed.py: ShardedCounter.
  */
 int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, size_t *keys_out);
+int tsx_hip_shard_scan_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off,
+                                     size_t win_len, void *dev_send, size_t send_cap_keys, void *dev_own,
+                                     size_t own_cap_keys, void *dev_send_counts, void *dev_hot_keys,
+                                     void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *dev_key_sum,
+                                     void *stream);
 int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, size_t n, void *dev_send,
                               size_t send_cap_keys, void *dev_send_counts, void *dev_hot_keys,
                               void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *stream);
-int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *stream);
+int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *dev_key_sum,
+                               void *stream);
 int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
                               void *stream);
 

@@ -19,24 +19,61 @@ from tsxcount_amd import synth  # noqa: E402
 
 dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
-for k, l in ((31, 18), (63, 18)):
-    n_reads = 160
+config5 = len(sys.argv) > 4 and sys.argv[4] == "config5"
+if config5:
+    # k = 127, 2-bit in-slot counters, ~138 reads per rank = ~100,000 distinct 127-mers in 2^17 slots (load ~0.8)
+    # on every rank before the merge and again after it; each shard is counted 5 times, so every count is
+    # >= 5 > 2^2 - 1 and EVERY k-mer carries into the secondary array (sized to hold them all).
+    k, l, s, per_rank, reps = 127, 17, 2, 138, 5
+    n_reads = per_rank * world
     first, cnt = TD.shard_reads(n_reads, rank, world)
-    m = T.TSXHashMapHIP(l, 0, k, device=0)
-    m.countFastq(synth.fastq(55, first, cnt))
+    m = T.TSXHashMapHIP(l, s, k, device=0, overflow_l=18)
+    assert m.layout.count_bits == 2 and m.layout.entry_limbs == 4
+    text = synth.fastq(55, first, cnt)
+    for _ in range(reps):
+        m.countFastq(text)
+    st = m.stats()
+    assert 0.7 < st["distinct"] / (1 << l) < 0.9, st
+    assert st["overflow_used"] == st["distinct"] and st["overflow_failures"] == 0 and st["insert_failures"] == 0
     received = TD.merge_tables(m)
-    whole = Oracle(k, 20, 4, seed=1)
+    whole = Oracle(k, 21, 4, seed=1)
     whole.count_fastq(synth.fastq(55, 0, n_reads))
     kmers, counts = whole.dump()
     mine = np.array([m.owner(kmers[i], world) == rank for i in range(len(kmers))])
     got = m.getKmerCounts(kmers)
-    assert np.array_equal(got[mine], counts[mine]), "owned k-mers must carry the merged count"
+    assert np.array_equal(got[mine], reps * counts[mine]), "owned k-mers must carry the merged count"
     assert (got[~mine] == 0).all(), "foreign k-mers must be gone after the merge"
-    assert m.stats()["distinct"] == int(mine.sum())
-    tot = torch.tensor([m.stats()["distinct"]], dtype=torch.int64)
+    st = m.stats()
+    assert st["distinct"] == int(mine.sum()) and received >= st["distinct"]
+    assert 0.6 < st["distinct"] / (1 << l) < 0.95, st   # load ~0.8 again: every rank owns 1/world of world x as many
+    assert st["count_sum"] == reps * int(counts[mine].sum())
+    assert st["overflow_failures"] == 0 and st["insert_failures"] == 0 and st["lock_timeouts"] == 0
+    dk, dc = m.getAllKmers()
+    a, b = np.lexsort(dk.T[::-1]), np.lexsort(kmers[mine].T[::-1])
+    assert np.array_equal(dk[a], kmers[mine][b]) and np.array_equal(dc[a], reps * counts[mine][b])
+    tot = torch.tensor([st["distinct"]], dtype=torch.int64)
     dist.all_reduce(tot)
     assert int(tot.item()) == len(kmers)
     m.close()
+else:
+    for k, l in ((31, 18), (63, 18)):
+        n_reads = 160
+        first, cnt = TD.shard_reads(n_reads, rank, world)
+        m = T.TSXHashMapHIP(l, 0, k, device=0)
+        m.countFastq(synth.fastq(55, first, cnt))
+        received = TD.merge_tables(m)
+        whole = Oracle(k, 20, 4, seed=1)
+        whole.count_fastq(synth.fastq(55, 0, n_reads))
+        kmers, counts = whole.dump()
+        mine = np.array([m.owner(kmers[i], world) == rank for i in range(len(kmers))])
+        got = m.getKmerCounts(kmers)
+        assert np.array_equal(got[mine], counts[mine]), "owned k-mers must carry the merged count"
+        assert (got[~mine] == 0).all(), "foreign k-mers must be gone after the merge"
+        assert m.stats()["distinct"] == int(mine.sum())
+        tot = torch.tensor([m.stats()["distinct"]], dtype=torch.int64)
+        dist.all_reduce(tot)
+        assert int(tot.item()) == len(kmers)
+        m.close()
 dist.barrier()
 dist.destroy_process_group()
 print("MERGE OK rank", rank)

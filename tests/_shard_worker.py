@@ -20,15 +20,18 @@ from tsxcount_amd import synth  # noqa: E402
 dist.init_process_group("gloo", rank=rank, world_size=world)
 torch.cuda.set_device(0)
 bits = world.bit_length() - 1
-for k, l, n_reads in ((31, 17, 240), (21, 15, 30), (32, 19, 700)):
+# windows > 1: the text is cut at multiples of 4 KiB, inside lines and records; every window's keys take
+# their own exchange while the next window is scanned
+for k, l, n_reads, windows in ((31, 17, 240, 3), (21, 15, 30, 1), (32, 19, 700, 5)):
     first, cnt = TD.shard_reads(n_reads, rank, world)
     text = synth.fastq(66, first, cnt)
     buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")
     m = T.TSXHashMapHIP(l, 0, k, device=0, shard_bits=bits, shard_index=rank)
-    sc = TD.ShardedCounter(m, len(text))
+    sc = TD.ShardedCounter(m, len(text), windows=windows)
     torch.cuda.synchronize()
     for rep in (1, 2):  # second pass merges into segments that already hold data
         sc.step(buf.data_ptr(), len(text))
+        assert sc.last["key_sum_diff"] == 0 and sc.last["windows"] == min(windows, -(-len(text) // sc.win_bytes))
         whole = Oracle(k, 21, 4, seed=1)
         whole.count_fastq(synth.fastq(66, 0, n_reads))
         kmers, counts = whole.dump()

@@ -1,0 +1,62 @@
+"""Test double for tsxcount_amd.distributed.TorchComm: N "ranks" are N threads of ONE process that
+share cuda:0, and the three collectives are device copies between their tensors behind a barrier.
+It lets the sharded multi-GPU pipeline run with world = 8 (shard_bits = 3, the value the 8-GPU
+node uses) on a one-GPU box, where at most 6 processes may touch the card.  Not a pytest file."""
+import threading
+
+import torch
+
+
+class ThreadWorld:
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+
+
+class ThreadComm:
+    gloo = False
+
+    def __init__(self, world, rank):
+        self.w, self.world, self.rank = world, world.n, rank
+
+    def _publish(self, item):
+        torch.cuda.current_stream().synchronize()   # what this rank offers is complete
+        self.w.slots[self.rank] = item
+        self.w.barrier.wait()
+
+    def _done(self):
+        torch.cuda.current_stream().synchronize()   # everything this rank took has been copied
+        self.w.barrier.wait()
+
+    def all_to_all(self, out, inp, out_sizes=None, in_sizes=None):
+        self._publish((inp, in_sizes))
+        at = 0
+        for p in range(self.world):
+            src, sizes = self.w.slots[p]
+            if sizes is None:
+                per = src.shape[0] // self.world
+                lo, cnt = self.rank * per, per
+            else:
+                lo, cnt = sum(sizes[:self.rank]), sizes[self.rank]
+            if out_sizes is not None:
+                assert cnt == out_sizes[p], "split sizes of sender %d and receiver %d disagree" % (p, self.rank)
+            out[at:at + cnt].copy_(src[lo:lo + cnt])
+            at += cnt
+        assert at == out.shape[0]
+        self._done()
+
+    def all_gather(self, out, inp):
+        self._publish(inp)
+        n = inp.shape[0]
+        for p in range(self.world):
+            out[p * n:(p + 1) * n].copy_(self.w.slots[p])
+        self._done()
+
+    def all_reduce(self, t, op="sum"):
+        self._publish(t.clone())
+        parts = torch.stack([self.w.slots[p].to(t.device) for p in range(self.world)])
+        red = {"sum": parts.sum(0), "min": parts.min(0).values, "max": parts.max(0).values}[op]
+        self._done()
+        t.copy_(red)
+        return t

@@ -58,7 +58,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_merge_equals_single_table():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_merge_equals_single_table(world):
+    """world = 8 is the size the target node runs: the exchange (sizes, rows, checksums, the agreement
+    all-reduce) with eight real processes, on CPU."""
     sys.path.insert(0, ROOT)
     from oracle.oracle import Oracle
     from tsxcount_amd import synth
@@ -70,10 +73,10 @@ def test_two_rank_merge_equals_single_table():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(2))
+    results = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -82,7 +85,7 @@ def test_two_rank_merge_equals_single_table():
     kmers, counts = whole.dump()
     expect = {kmers[i].tobytes(): int(counts[i]) for i in range(len(kmers))}
     merged = {}
-    for r in (0, 1):
+    for r in range(world):
         assert not (set(results[r]) & set(merged))  # owners are disjoint
         merged.update(results[r])
     assert merged == expect

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtsxcount_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tsxcount_hip.h")
 
-OK, EINVAL, ENODEVICE, ENOMEM, EHIP, EFULL, EOVERFLOW, ERANGE = 0, -1, -2, -3, -4, -5, -6, -7
+OK, EINVAL, ENODEVICE, ENOMEM, EHIP, EFULL, EOVERFLOW, ERANGE, ELOCK = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class TSXException(RuntimeError):
@@ -39,7 +39,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("kmers_added", ctypes.c_uint64), ("insert_failures", ctypes.c_uint64),
                 ("overflow_carries", ctypes.c_uint64), ("overflow_failures", ctypes.c_uint64),
                 ("distinct", ctypes.c_uint64), ("overflow_used", ctypes.c_uint64),
-                ("lock_timeouts", ctypes.c_uint64), ("fallback_inserts", ctypes.c_uint64)]
+                ("lock_timeouts", ctypes.c_uint64), ("fallback_inserts", ctypes.c_uint64),
+                ("count_sum", ctypes.c_uint64)]
 
     def as_dict(self):
         return {f: int(getattr(self, f)) for f, _ in self._fields_}
@@ -75,7 +76,8 @@ def lib():
     L.tsx_hip_create_shard.argtypes = [ctypes.POINTER(vp), ci, ci, ci, ci, u64, ci, ci, ci]
     L.tsx_hip_shard_send_capacity.argtypes = [vp, sz, ctypes.POINTER(sz)]
     L.tsx_hip_shard_scan_device.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp, vp]
-    L.tsx_hip_shard_build_device.argtypes = [vp, vp, sz, vp]
+    L.tsx_hip_shard_scan_window_device.argtypes = [vp, vp, sz, sz, sz, vp, sz, vp, sz, vp, vp, vp, sz, vp, vp, vp]
+    L.tsx_hip_shard_build_device.argtypes = [vp, vp, sz, vp, vp]
     L.tsx_hip_add_hashed_device.argtypes = [vp, vp, vp, sz, vp]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None
@@ -92,6 +94,7 @@ def lib():
     L.tsx_hip_dump_host.argtypes = [vp, u64p, u64p, sz, ctypes.POINTER(sz)]
     L.tsx_hip_dump_device.argtypes = [vp, vp, vp, sz, vp, vp]
     L.tsx_hip_partition_device.argtypes = [vp, ci, vp, vp, sz, vp, vp]
+    L.tsx_hip_dump_range_device.argtypes = [vp, u64, u64, vp, vp, sz, vp, vp]
     L.tsx_hip_owner_host.argtypes = [vp, u64p, ci]
     L.tsx_hip_hash_apply.argtypes = [vp, u64p, u64p]
     L.tsx_hip_hash_invert.argtypes = [vp, u64p, u64p]
@@ -224,6 +227,17 @@ class TSXHashMapHIP:
         got = ctypes.c_size_t(0)
         _check(self._lib.tsx_hip_dump_host(self._h, _p(kmers), _p(counts), max(n, 1), ctypes.byref(got)))
         return kmers[:got.value], counts[:got.value]
+
+    def dumpRangeDevice(self, slot_lo, slot_hi, kmers_ptr, counts_ptr, cap, n_ptr, stream=None):
+        """getAllKmers for the slots [slot_lo, slot_hi) into device buffers (tsx_hip_dump_range_device)."""
+        vp = ctypes.c_void_p
+        _check(self._lib.tsx_hip_dump_range_device(self._h, slot_lo, slot_hi, vp(kmers_ptr), vp(counts_ptr), cap,
+                                                   vp(n_ptr), vp(stream) if stream else None))
+
+    def getKmerCountsDevice(self, kmers_ptr, n, out_ptr, stream=None):
+        vp = ctypes.c_void_p
+        _check(self._lib.tsx_hip_get_counts_device(self._h, vp(kmers_ptr), n, vp(out_ptr),
+                                                   vp(stream) if stream else None))
 
     def print_stats(self):
         s = self.stats()

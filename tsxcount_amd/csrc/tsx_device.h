@@ -30,7 +30,8 @@ enum StatIdx {
     ST_SCRATCH = 5,    // reductions (distinct, ...)
     ST_SCRATCH2 = 6,
     ST_FALLBACK = 7,   // keys the partitioned path handed to insert_key (a list or log region was full)
-    ST_N = 8
+    ST_SCRATCH3 = 8,   // reduction: sum of all counts
+    ST_N = 9
 };
 
 struct TableParams {

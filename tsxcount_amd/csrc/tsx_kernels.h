@@ -56,9 +56,10 @@ __device__ __forceinline__ uint4 load16(const uint8_t *buf, uint64_t off, uint64
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 // Is the byte before offset off a newline?  Offset 0 counts as a line start
-// unless the caller says a previous piece ended mid-line.
+// unless the caller says a previous piece ended mid-line (head_open = 1) or that the
+// piece is a window into a longer device text whose previous byte can be read (head_open < 0).
 __device__ __forceinline__ bool prev_is_nl(const uint8_t *buf, uint64_t off, uint64_t n, int head_open) {
-    if (off == 0) return !head_open;
+    if (off == 0) return head_open < 0 ? (*(buf - 1) == (uint8_t)'\n') : !head_open;
     if (off - 1 >= n) return true;
     return buf[off - 1] == (uint8_t)'\n';
 }
@@ -627,18 +628,28 @@ __global__ __launch_bounds__(NT) void get_counts_kernel(TableParams p, const uin
 }
 
 // getKmerCount(): occupied primary slots -> stats[ST_SCRATCH]; occupied
-// secondary slots -> stats[ST_SCRATCH2].
+// secondary slots -> stats[ST_SCRATCH2]; sum of every stored count (in-slot counters plus
+// carries << C) -> stats[ST_SCRATCH3].
 __global__ __launch_bounds__(NT) void occupied_kernel(TableParams p) {
-    unsigned long long c = 0, c2 = 0;
+    unsigned long long c = 0, c2 = 0, cs = 0;
     const uint64_t slots = p.slot_mask + 1, sslots = p.sec_mask + 1;
-    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * NT)
-        c += (p.table[i * (uint64_t)p.W] != 0) ? 1ULL : 0ULL;
-    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < sslots; i += (uint64_t)gridDim.x * NT)
-        c2 += (p.sec_keys[i] != 0) ? 1ULL : 0ULL;
-    for (int d = 32; d > 0; d >>= 1) { c += __shfl_down(c, d, 64); c2 += __shfl_down(c2, d, 64); }
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < slots; i += (uint64_t)gridDim.x * NT) {
+        const uint64_t v = p.table[i * (uint64_t)p.W];
+        c += (v != 0) ? 1ULL : 0ULL;
+        cs += v >> p.cshift;
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < sslots; i += (uint64_t)gridDim.x * NT) {
+        const bool used = p.sec_keys[i] != 0;
+        c2 += used ? 1ULL : 0ULL;
+        cs += used ? ((unsigned long long)p.sec_cnt[i] << p.C) : 0ULL;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        c += __shfl_down(c, d, 64); c2 += __shfl_down(c2, d, 64); cs += __shfl_down(cs, d, 64);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (c) atomicAdd(&p.stats[ST_SCRATCH], c);
         if (c2) atomicAdd(&p.stats[ST_SCRATCH2], c2);
+        if (cs) atomicAdd(&p.stats[ST_SCRATCH3], cs);
     }
 }
 
@@ -691,12 +702,12 @@ __device__ __forceinline__ int owner_of(const uint64_t *x, int wk, int nranks) {
 template <int WK>
 __global__ __launch_bounds__(NT) void dump_kernel(TableParams p, int nranks, int mode, uint64_t *kmers_out,
                                                   uint64_t *counts_out, uint64_t cap,
-                                                  unsigned long long *seg) {
-    const uint64_t slots = p.slot_mask + 1;
+                                                  unsigned long long *seg, uint64_t slot_lo, uint64_t slot_hi) {
+    const uint64_t slots = slot_hi;
     const int lane = threadIdx.x & 63;
     const uint64_t lt = (1ULL << lane) - 1ULL;
     // wave-uniform trip count: every lane of a wave runs the same iterations
-    for (uint64_t base = (uint64_t)blockIdx.x * NT + (threadIdx.x & ~63u); base < slots; base += (uint64_t)gridDim.x * NT) {
+    for (uint64_t base = slot_lo + (uint64_t)blockIdx.x * NT + (threadIdx.x & ~63u); base < slots; base += (uint64_t)gridDim.x * NT) {
         const uint64_t pos = base + lane;
         const bool occ = pos < slots && p.table[pos * (uint64_t)p.W] != 0;
         uint64_t x[WK], c = 0;

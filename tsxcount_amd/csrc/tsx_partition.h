@@ -316,10 +316,17 @@ __global__ __launch_bounds__(1024) void offsets_finish_kernel(uint32_t nb, unsig
 __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *src, const unsigned long long *src_cnt,
                                                               uint64_t src_cap, uint32_t nregions, uint64_t *dst,
                                                               const unsigned long long *offs,
-                                                              const unsigned long long *offs_base, uint32_t nown,
-                                                              uint32_t shift) {
+                                                              const unsigned long long *offs_base,
+                                                              const unsigned long long *owner_cnt, uint32_t nown,
+                                                              uint32_t shift, uint64_t *dst_own, uint32_t own,
+                                                              unsigned long long *key_sum) {
     __shared__ unsigned long long s_cur[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
+    // keys of owner `own` (this GPU) go to dst_own, packed from 0: they never travel
+    // and the send buffer closes the gap they would have left (owners above `own` move down by their number)
+    const unsigned long long own_base = dst_own ? offs_base[own] : 0ULL;
+    const unsigned long long own_cnt = dst_own ? owner_cnt[own] : 0ULL;
+    unsigned long long sum = 0;   // integrity: sum of every key handed on (mod 2^64), checked against the builders' sums
     for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
         lds_barrier();
         if (tid < nown) s_cur[tid] = offs_base[tid] + offs[(size_t)tid * nregions + r];
@@ -345,8 +352,17 @@ __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *sr
             unsigned long long at = 0;
             if (lane < nown && cnt_d) at = atomicAdd(&s_cur[lane], (unsigned long long)cnt_d);
             at = __shfl(at, (int)(o & 63u), 64);
-            if (have) dst[at + __builtin_popcountll(my_mk & ((1ULL << lane) - 1ULL))] = key;
+            if (have) {
+                at += __builtin_popcountll(my_mk & ((1ULL << lane) - 1ULL));
+                if (dst_own && o == own) dst_own[at - own_base] = key;
+                else dst[at - (o > own ? own_cnt : 0ULL)] = key;
+                sum += key;
+            }
         }
+    }
+    if (key_sum) {
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+        if (lane == 0 && sum) atomicAdd(key_sum, sum);
     }
 }
 
@@ -354,9 +370,11 @@ __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *sr
 // shard received): hist[b * G + g], the layout offsets_kernel scans.
 __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uint64_t n, uint64_t region_len,
                                                        uint32_t G, uint32_t nb, uint32_t shift, uint32_t *hist,
-                                                       unsigned long long *region_start, unsigned long long *region_cnt) {
+                                                       unsigned long long *region_start, unsigned long long *region_cnt,
+                                                       unsigned long long *key_sum) {
     __shared__ uint32_t s_h[512];
     const uint32_t tid = threadIdx.x;
+    unsigned long long sum = 0;   // integrity: sum of every key received (see split_owner_kernel)
     for (uint32_t g = blockIdx.x; g < G; g += gridDim.x) {
         lds_barrier();
         for (uint32_t b = tid; b < nb; b += PART_NT) s_h[b] = 0;
@@ -370,23 +388,38 @@ __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uin
             atomicAdd(&s_h[(uint32_t)(k1 >> shift) & (nb - 1)], 1u);
             atomicAdd(&s_h[(uint32_t)(k2 >> shift) & (nb - 1)], 1u);
             atomicAdd(&s_h[(uint32_t)(k3 >> shift) & (nb - 1)], 1u);
+            sum += k0 + k1 + k2 + k3;
         }
-        for (; i < hi; i += PART_NT) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & (nb - 1)], 1u);
+        for (; i < hi; i += PART_NT) {
+            const uint64_t k0 = keys[i];
+            atomicAdd(&s_h[(uint32_t)(k0 >> shift) & (nb - 1)], 1u);
+            sum += k0;
+        }
         lds_barrier();
         for (uint32_t b = tid; b < nb; b += PART_NT) hist[(size_t)b * G + g] = s_h[b];
         if (tid == 0) { region_start[g] = lo; region_cnt[g] = hi - lo; }
+    }
+    if (key_sum) {
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+        if ((tid & 63) == 0 && sum) atomicAdd(key_sum, sum);
     }
 }
 
 // addKmer for HASHED keys with counts (the exchanged hot-key lists of a sharded run);
 // keys of other shards are skipped.
 __global__ __launch_bounds__(PART_NT) void add_hashed_kernel(TableParams p, const uint64_t *keys, const uint64_t *counts,
-                                                             uint64_t n) {
+                                                             uint64_t n, unsigned long long *key_sum) {
+    unsigned long long sum = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * PART_NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PART_NT) {
         const uint64_t h[1] = {keys[i]};
         const uint64_t d = counts ? counts[i] : 1ULL;
+        sum += h[0];
         if (d == 0 || owner_shard<1>(p, h) != p.shard) continue;
         insert_key<1>(p, h, d);
+    }
+    if (key_sum) {
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+        if ((threadIdx.x & 63) == 0 && sum) atomicAdd(key_sum, sum);
     }
 }
 

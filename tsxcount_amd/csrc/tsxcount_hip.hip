@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
@@ -73,12 +74,13 @@ struct tsx_hip_map {
     unsigned long long *d_cnt = nullptr;   // [log regions | level-1 lists | segment lists]
     size_t cnt_entries = 0;
     // optional per-pass timing (HIP events on the launch stream)
+    bool attr_done = false;          // dynamic-LDS limits of the partition / build kernels set on this map's device
     int timing = 0;
     int dbg = 0;                     // TSX_HIP_DEBUG: bit0 = skip the global insert (ablation builds only)
     std::vector<hipEvent_t> ev;      // seven per piece: before pass 1, before pass 3, after pass 3, start of the
                                      // partition phase (later than the scan's end only in a sharded run: the
                                      // exchange lies between), after level 1, level 2, build
-    long ev_open = -1;               // tuple of a shard scan whose partition phase has not run yet
+    std::deque<long> ev_open;        // tuples of shard scans whose partition phase has not run yet (oldest first)
     size_t ev_used = 0;
 };
 
@@ -96,6 +98,7 @@ extern "C" const char *tsx_hip_strerror(int code) {
         case TSX_HIP_EFULL: return "Could not insert kmer: table full";
         case TSX_HIP_EOVERFLOW: return "count overflow array full";
         case TSX_HIP_ERANGE: return "output buffer too small";
+        case TSX_HIP_ELOCK: return "a multi-limb slot stayed locked past the spin bound";
     }
     return "unknown";
 }
@@ -447,6 +450,7 @@ extern "C" int tsx_hip_sync(tsx_hip_map *m) {
     if (rc != TSX_HIP_OK) return rc;
     if (st[ST_FAIL]) return TSX_HIP_EFULL;
     if (st[ST_SECFAIL]) return TSX_HIP_EOVERFLOW;
+    if (st[ST_LOCKTO]) return TSX_HIP_ELOCK;   // an expired spin re-probes: the key may sit in two slots
     return TSX_HIP_OK;
 }
 
@@ -541,11 +545,10 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.d_offs = pl.c_seg + (size_t)pl.nseg * pl.cpr2;
     pl.d_hist = reinterpret_cast<uint32_t *>(pl.d_offs + mat);
     HIP_TRY(hipMemsetAsync(m->d_cnt, 0, pl.cnt_need * 8, st));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!m->attr_done) {   // per map, hence per device: the attribute belongs to the device's copy of the kernel
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
-        attr_done = true;
+        m->attr_done = true;
     }
     return TSX_HIP_OK;
 }
@@ -619,6 +622,13 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
 }
 
 struct HotOut { uint64_t *keys = nullptr, *cnts = nullptr; uint64_t cap = 0; unsigned long long *n = nullptr; };
+// Sharded scan: where the keys go.  send: groups by owner GPU (own group left out when `own` is given),
+// own: this GPU's keys (they never travel), counts[o]: keys per owner, key_sum += sum of all keys.
+struct ShardOut {
+    uint64_t *send = nullptr; uint64_t send_cap = 0;
+    uint64_t *own = nullptr; uint64_t own_cap = 0;
+    unsigned long long *counts = nullptr, *key_sum = nullptr;
+};
 
 // One FASTQ piece already on the device: passes 1-3.  own_end = number of start
 // positions this piece owns (bytes past it are halo for windows that begin
@@ -626,8 +636,10 @@ struct HotOut { uint64_t *keys = nullptr, *cnts = nullptr; uint64_t cap = 0; uns
 // shard_send != nullptr: sharded scan -- the keys are not built into the local table but
 // split by owner into shard_send (counts per owner to shard_counts), hot keys to `hot`.
 static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
-                           hipStream_t st, uint64_t *shard_send = nullptr, uint64_t shard_cap = 0,
-                           unsigned long long *shard_counts = nullptr, HotOut hot = HotOut()) {
+                           hipStream_t st, ShardOut sh = ShardOut(), HotOut hot = HotOut()) {
+    uint64_t *shard_send = sh.send;
+    const uint64_t shard_cap = sh.send_cap;
+    unsigned long long *shard_counts = sh.counts;
     if (own_end == 0) return TSX_HIP_OK;
     const uint64_t ntiles = (own_end + TILE - 1) / TILE;
     if (ntiles > m->tile_cap) {
@@ -688,14 +700,16 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
     if (shard_send) {
         // level 0: split every log region by owner into the caller's send buffer (exact offsets)
-        if ((uint64_t)greg * pl.log_cap > shard_cap) return TSX_HIP_ERANGE;
+        if ((uint64_t)greg * pl.log_cap > shard_cap || (sh.own && (uint64_t)greg * pl.log_cap > sh.own_cap))
+            return TSX_HIP_ERANGE;
         hipLaunchKernelGGL(offsets_rows_kernel, dim3(nown), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs,
                            (uint32_t)greg, pl.c_bcnt);
         hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, nown, pl.c_bstart, pl.c_bcnt);
         hipLaunchKernelGGL(split_owner_kernel, dim3(std::min(greg, m->cus * 8)), dim3(PART_NT), 0, st,
                            (const uint64_t *)m->d_buf[0], (const unsigned long long *)pl.c_log, pl.log_cap,
                            (uint32_t)greg, shard_send, (const unsigned long long *)pl.d_offs,
-                           (const unsigned long long *)pl.c_bstart, nown, (uint32_t)p.l);
+                           (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, nown,
+                           (uint32_t)p.l, sh.own, p.shard, sh.key_sum);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(shard_counts, pl.c_bcnt, nown * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
     } else {
@@ -704,31 +718,47 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     if (ev && shard_send) {   // the partition phase follows in tsx_hip_shard_build_device, which records 3..6 again
         for (int i = 3; i < 7; ++i) HIP_TRY(hipEventRecord(ev[i], st));
-        m->ev_open = (long)(ev - m->ev.data());
+        m->ev_open.push_back((long)(ev - m->ev.data()));
     }
     if (ev && !shard_send) HIP_TRY(hipEventRecord(ev[6], st));
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, size_t n, void *dev_send,
-                                         size_t send_cap_keys, void *dev_send_counts, void *dev_hot_keys,
-                                         void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *stream) {
-    if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15) || !dev_send || !dev_send_counts || !dev_hot_keys ||
-        !dev_hot_counts || !dev_hot_n)
+extern "C" int tsx_hip_shard_scan_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off,
+                                                size_t win_len, void *dev_send, size_t send_cap_keys, void *dev_own,
+                                                size_t own_cap_keys, void *dev_send_counts, void *dev_hot_keys,
+                                                void *dev_hot_counts, size_t hot_cap, void *dev_hot_n,
+                                                void *dev_key_sum, void *stream) {
+    if (!m || (!dev_text && n_total) || ((uintptr_t)dev_text & 15) || (win_off & 15) || !dev_send || !dev_send_counts ||
+        !dev_hot_keys || !dev_hot_counts || !dev_hot_n || win_off > n_total || win_len > n_total - win_off)
         return TSX_HIP_EINVAL;
     if (m->p.wk != 1 || m->p.W != 1) return TSX_HIP_EINVAL;  // one-limb keys only (k <= 32)
-    if (n >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;        // one window per call
+    if (win_len >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;  // one window per call
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
-    HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    if (win_off == 0) HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));   // line index restarts with the text
     HIP_TRY(hipMemsetAsync(dev_hot_n, 0, 8, st));
     HIP_TRY(hipMemsetAsync(dev_send_counts, 0, sizeof(unsigned long long) << (m->p.lg - m->p.l), st));
-    if (n == 0) return TSX_HIP_OK;
+    if (win_len == 0) return TSX_HIP_OK;
     HotOut hot;
     hot.keys = (uint64_t *)dev_hot_keys; hot.cnts = (uint64_t *)dev_hot_counts; hot.cap = hot_cap;
     hot.n = (unsigned long long *)dev_hot_n;
-    return run_fastq_piece(m, (const uint8_t *)dev_text, n, n, 0, st, (uint64_t *)dev_send, send_cap_keys,
-                           (unsigned long long *)dev_send_counts, hot);
+    ShardOut sh;
+    sh.send = (uint64_t *)dev_send; sh.send_cap = send_cap_keys;
+    sh.own = (uint64_t *)dev_own; sh.own_cap = own_cap_keys;
+    sh.counts = (unsigned long long *)dev_send_counts; sh.key_sum = (unsigned long long *)dev_key_sum;
+    // the window owns win_len start positions and sees the k-1 bytes after them; whether it starts inside a
+    // line is read from the byte in front of it, on the device
+    const size_t halo = (size_t)m->p.k - 1;
+    const size_t len = std::min(win_len + halo, n_total - win_off);
+    return run_fastq_piece(m, (const uint8_t *)dev_text + win_off, len, win_len, win_off ? -1 : 0, st, sh, hot);
+}
+
+extern "C" int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, size_t n, void *dev_send,
+                                         size_t send_cap_keys, void *dev_send_counts, void *dev_hot_keys,
+                                         void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *stream) {
+    return tsx_hip_shard_scan_window_device(m, dev_text, n, 0, n, dev_send, send_cap_keys, nullptr, 0, dev_send_counts,
+                                            dev_hot_keys, dev_hot_counts, hot_cap, dev_hot_n, nullptr, stream);
 }
 
 extern "C" int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, size_t *keys_out) {
@@ -741,16 +771,19 @@ extern "C" int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, si
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *stream) {
+extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *dev_key_sum,
+                                          void *stream) {
     if (!m || (!dev_keys && n_keys) || ((uintptr_t)dev_keys & 7)) return TSX_HIP_EINVAL;
+    unsigned long long *key_sum = (unsigned long long *)dev_key_sum;
     if (n_keys == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
     if (!can_partition(m)) {  // tiny tables: plain atomic inserts of the hashed keys
         const int grid = grid_for(m, n_keys, 8);
         hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
-                           (const uint64_t *)nullptr, (uint64_t)n_keys);
+                           (const uint64_t *)nullptr, (uint64_t)n_keys, key_sum);
         HIP_TRY(hipGetLastError());
+        if (!m->ev_open.empty()) m->ev_open.pop_front();
         return TSX_HIP_OK;
     }
     const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_keys + 4095) / 4096, (uint64_t)m->cus * 3));
@@ -758,14 +791,14 @@ extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, 
     int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl);
     if (rc != TSX_HIP_OK) return rc;
     hipEvent_t *ev = nullptr;
-    if (m->timing && m->ev_open >= 0 && (size_t)m->ev_open + 7 <= m->ev_used) {
-        ev = &m->ev[(size_t)m->ev_open];
+    if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + 7 <= m->ev_used) {
+        ev = &m->ev[(size_t)m->ev_open.front()];
         HIP_TRY(hipEventRecord(ev[3], st));   // the histogram of the received keys counts as level 1
     }
-    m->ev_open = -1;
+    if (!m->ev_open.empty()) m->ev_open.pop_front();
     const uint64_t region_len = (n_keys + g - 1) / g;
     hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, (const uint64_t *)dev_keys, (uint64_t)n_keys, region_len,
-                       (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1), pl.d_hist, pl.c_rstart, pl.c_log);
+                       (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1), pl.d_hist, pl.c_rstart, pl.c_log, key_sum);
     HIP_TRY(hipGetLastError());
     rc = run_partition_build(m, pl, (const uint64_t *)dev_keys, pl.c_rstart, 0, st, ev);
     if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[6], st));
@@ -781,7 +814,7 @@ extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, c
     hipStream_t st = pick_stream(m, stream);
     const int grid = grid_for(m, n, 8);
     hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
-                       (const uint64_t *)dev_counts, (uint64_t)n);
+                       (const uint64_t *)dev_counts, (uint64_t)n, (unsigned long long *)nullptr);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
@@ -796,6 +829,7 @@ extern "C" int tsx_hip_set_timing(tsx_hip_map *m, int enable) {
     if (!m) return TSX_HIP_EINVAL;
     m->timing = enable ? 1 : 0;
     m->ev_used = 0;
+    m->ev_open.clear();
     return TSX_HIP_OK;
 }
 
@@ -815,7 +849,7 @@ extern "C" int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64
     if (stage_ms) for (int sgm = 0; sgm < 6; ++sgm) stage_ms[sgm] = acc[sgm];
     if (launches) *launches = m->ev_used / 7;
     m->ev_used = 0;
-    m->ev_open = -1;
+    m->ev_open.clear();
     return TSX_HIP_OK;
 }
 
@@ -837,6 +871,7 @@ static const size_t DEV_WINDOW_DEFAULT = (size_t)4 << 30;
 
 extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream) {
     if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15)) return TSX_HIP_EINVAL;
+    if (m->p.lg != m->p.l) return TSX_HIP_EINVAL;   // a shard: keys of other owners must travel (shard_scan / shard_build)
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
     HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
@@ -850,14 +885,8 @@ extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, 
     for (size_t off = 0; off < n || off == 0; off += DEV_WINDOW) {
         const size_t own = std::min(DEV_WINDOW, n - off);
         const size_t len = std::min(own + halo, n - off);
-        int head_open = 0;
-        if (off > 0) {  // does the previous window end inside a line?
-            uint8_t prev = 0;
-            HIP_TRY(hipMemcpyAsync(&prev, base + off - 1, 1, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            head_open = (prev != (uint8_t)'\n') ? 1 : 0;
-        }
-        int rc = run_fastq_piece(m, base + off, len, own, head_open, st);
+        // whether the previous window ends inside a line is read on the device (the byte in front of this one)
+        int rc = run_fastq_piece(m, base + off, len, own, off > 0 ? -1 : 0, st);
         if (rc != TSX_HIP_OK) return rc;
         if (n == 0) break;
     }
@@ -909,6 +938,7 @@ static void parallel_memcpy(uint8_t *dst, const char *src, size_t len) {
 
 extern "C" int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n) {
     if (!m || (!text && n)) return TSX_HIP_EINVAL;
+    if (m->p.lg != m->p.l) return TSX_HIP_EINVAL;   // see tsx_hip_count_fastq_device
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
     int rc = ensure_staging(m, n);
@@ -1012,6 +1042,7 @@ extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
     if (!m || !out) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipMemsetAsync(m->p.stats + ST_SCRATCH, 0, 2 * sizeof(unsigned long long), m->stream));
+    HIP_TRY(hipMemsetAsync(m->p.stats + ST_SCRATCH3, 0, sizeof(unsigned long long), m->stream));
     const int grid = grid_for(m, m->lay.slots, 8);
     hipLaunchKernelGGL(occupied_kernel, dim3(grid), dim3(NT), 0, m->stream, m->p);
     HIP_TRY(hipGetLastError());
@@ -1026,19 +1057,22 @@ extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
     out->fallback_inserts = st[ST_FALLBACK];
     out->distinct = st[ST_SCRATCH];
     out->overflow_used = st[ST_SCRATCH2];
+    out->count_sum = st[ST_SCRATCH3];
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_partition_device(tsx_hip_map *m, int nranks, void *dev_kmers_out, void *dev_counts_out,
-                                        size_t cap, void *dev_seg_counts, void *stream) {
+// Entries of the table slots [slot_lo, slot_hi), grouped by owner rank (nranks = 1: plain dump).
+static int dump_slots(tsx_hip_map *m, int nranks, uint64_t slot_lo, uint64_t slot_hi, void *dev_kmers_out,
+                      void *dev_counts_out, size_t cap, void *dev_seg_counts, void *stream) {
     if (!m || nranks < 1 || nranks > 64 || !dev_kmers_out || !dev_counts_out || !dev_seg_counts) return TSX_HIP_EINVAL;
+    if (slot_lo > slot_hi || slot_hi > m->lay.slots) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
-    const int grid = grid_for(m, m->lay.slots, 8);
+    const int grid = grid_for(m, std::max<uint64_t>(1, slot_hi - slot_lo), 8);
     unsigned long long *seg = m->d_seg;
     HIP_TRY(hipMemsetAsync(seg, 0, 64 * sizeof(unsigned long long), st));
     DISPATCH_WK(m, hipLaunchKernelGGL((dump_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p, nranks, 0,
-                                      (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, seg));
+                                      (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, seg, slot_lo, slot_hi));
     // segment sizes -> caller; exclusive prefix -> cursors (tiny: done on the host)
     unsigned long long h_seg[64];
     HIP_TRY(hipMemcpyAsync(h_seg, seg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1049,16 +1083,29 @@ extern "C" int tsx_hip_partition_device(tsx_hip_map *m, int nranks, void *dev_km
     HIP_TRY(hipMemcpyAsync(dev_seg_counts, h_seg, (size_t)nranks * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(seg, cur, 64 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     DISPATCH_WK(m, hipLaunchKernelGGL((dump_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p, nranks, 1,
-                                      (uint64_t *)dev_kmers_out, (uint64_t *)dev_counts_out, (uint64_t)cap, seg));
+                                      (uint64_t *)dev_kmers_out, (uint64_t *)dev_counts_out, (uint64_t)cap, seg, slot_lo,
+                                      slot_hi));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));  // cur[] lives on this stack frame
     return TSX_HIP_OK;
 }
 
+extern "C" int tsx_hip_partition_device(tsx_hip_map *m, int nranks, void *dev_kmers_out, void *dev_counts_out,
+                                        size_t cap, void *dev_seg_counts, void *stream) {
+    if (!m) return TSX_HIP_EINVAL;
+    return dump_slots(m, nranks, 0, m->lay.slots, dev_kmers_out, dev_counts_out, cap, dev_seg_counts, stream);
+}
+
 extern "C" int tsx_hip_dump_device(tsx_hip_map *m, void *dev_kmers_out, void *dev_counts_out, size_t cap,
                                    void *dev_n, void *stream) {
-    if (!dev_n) return TSX_HIP_EINVAL;
-    return tsx_hip_partition_device(m, 1, dev_kmers_out, dev_counts_out, cap, dev_n, stream);
+    if (!m || !dev_n) return TSX_HIP_EINVAL;
+    return dump_slots(m, 1, 0, m->lay.slots, dev_kmers_out, dev_counts_out, cap, dev_n, stream);
+}
+
+extern "C" int tsx_hip_dump_range_device(tsx_hip_map *m, uint64_t slot_lo, uint64_t slot_hi, void *dev_kmers_out,
+                                         void *dev_counts_out, size_t cap, void *dev_n, void *stream) {
+    if (!m || !dev_n) return TSX_HIP_EINVAL;
+    return dump_slots(m, 1, slot_lo, slot_hi, dev_kmers_out, dev_counts_out, cap, dev_n, stream);
 }
 
 extern "C" int tsx_hip_dump_host(tsx_hip_map *m, uint64_t *kmers_out, uint64_t *counts_out, size_t cap,

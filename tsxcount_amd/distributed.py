@@ -1,14 +1,25 @@
-"""Multi-GPU plumbing for --mode=HIP: reads shard across ranks (one process per
-GPU), every rank counts its shard into its own table with no collective on the
-data path, then ONE exchange step merges the per-GPU tables: each rank groups
-its table entries by owner rank (tsx_hip_partition_device), the groups travel
-through an all-to-all (RCCL over xGMI on GPUs, gloo on CPU in the tests), and
-the owner re-inserts what it receives.  After the merge rank r holds the
-complete counts of every k-mer with owner(kmer) == r.
+"""Multi-GPU plumbing for --mode=HIP: one process per GPU, reads shard across ranks.
 
-torch.distributed is used for the collective only.
+Two ways to combine the ranks' work:
+
+ShardedCounter   ONE table sharded by slot range.  Every rank scans its own reads in
+                 windows; the hashed keys of a window travel to the rank that owns their
+                 slot range through ONE all-to-all (RCCL over xGMI) and are built there.
+                 The exchange of window i runs on its own stream while the GPU scans
+                 window i+1 and builds window i-1; the keys a rank owns itself never
+                 enter the collective (the scan writes them straight into the receive
+                 buffer).  No table is extracted or re-inserted.
+merge_tables     the literal "merge of per-GPU tables": every rank counts into its own
+                 table, entries are grouped by owner rank, exchanged and re-inserted.
+                 Any k, any world size; one extraction + one atomic insert per entry.
+
+torch.distributed is used for the collectives only (backend "nccl" = RCCL on device
+tensors; "gloo" stages through host memory and exists for tests that put several ranks
+on one GPU).  A rank whose local step fails does not leave its peers inside a
+collective: the status travels with the sizes, and every rank raises together.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -21,23 +32,74 @@ def shard_reads(n_reads_total, rank, world):
     return first, base + (1 if rank < rem else 0)
 
 
-A2A_CHUNK = 16 << 20  # elements (128 MiB of int64) per pair and round
+class TorchComm:
+    """The three collectives the multi-GPU path needs, over a torch.distributed group."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.gloo = dist.get_backend(group) == "gloo"
+
+    def all_to_all(self, out, inp, out_sizes=None, in_sizes=None):
+        """all_to_all_single on the current stream; sizes count rows of dim 0."""
+        if self.gloo:   # CPU collective: tests with several ranks on one GPU
+            torch.cuda.current_stream(out.device).synchronize() if out.is_cuda else None
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_sizes, input_split_sizes=in_sizes,
+                                   group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, output_split_sizes=out_sizes, input_split_sizes=in_sizes,
+                                   group=self.group)
+
+    def all_gather(self, out, inp):
+        if self.gloo:
+            torch.cuda.current_stream(out.device).synchronize() if out.is_cuda else None
+            parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self.world)]
+            dist.all_gather(parts, inp.cpu(), group=self.group)
+            out.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(out, inp.contiguous(), group=self.group)
+
+    def all_reduce(self, t, op="sum"):
+        """In place; returns t.  Small tensors only."""
+        rop = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[op]
+        if self.gloo and t.is_cuda:
+            c = t.cpu()
+            dist.all_reduce(c, op=rop, group=self.group)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t, op=rop, group=self.group)
+        return t
+
+
+def _comm(group_or_comm):
+    return group_or_comm if hasattr(group_or_comm, "all_to_all") else TorchComm(group_or_comm)
+
+
+def agree(ok, comm, device):
+    """True iff `ok` holds on every rank (one tiny MIN all-reduce): call it before a collective
+    whose peers would otherwise wait for a rank that has already failed."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cpu" if comm.gloo else device)
+    comm.all_reduce(t, "min")
+    return bool(int(t.item()))
+
+
+A2A_CHUNK = 128 << 20  # elements (1 GiB of int64) per pair and collective
 
 
 def exchange_rows(inp, in_sizes, out_sizes, group=None, chunk=A2A_CHUNK):
-    """All-to-all of int64 rows, robust against large messages.
-
-    `inp` is 1-D int64, grouped by destination rank (in_sizes[p] elements for rank p);
+    """All-to-all of 1-D int64 data grouped by destination rank (in_sizes[p] elements for rank p);
     the result is grouped by source rank (out_sizes[p] elements from rank p).
 
-    Measured on this stack (ROCm 7.2 RCCL, torch 2.10): one all_to_all_single of
-    >= 1.2 GB delivers only half of the payload intact (scripts/a2a_test.py; 128 MiB is
-    fine, all_gather is fine at 6.4 GB).  So: the part a rank keeps never goes through
-    the collective, peers are served in rounds of at most `chunk` elements per pair,
-    and a per-pair checksum (sum modulo 2^64) travels separately and is verified.
-    """
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    gloo = dist.get_backend(group) == "gloo"
+    When every pair's message fits `chunk` elements (the usual case) it is ONE all_to_all_single
+    straight from `inp` into the result; larger messages go in rounds (the part a rank keeps is then
+    copied on the device).  A per-pair checksum (sum modulo 2^64) travels separately and is
+    verified: a single all_to_all_single of >= 1.2 GB was seen to deliver half of its payload on
+    this stack with ONE rank (scripts/a2a_test.py); whether that also holds between real peers
+    is logged by the checksum here rather than assumed."""
+    comm = _comm(group)
+    world, rank = comm.world, comm.rank
     dev = inp.device
     in_off = [0] * (world + 1)
     out_off = [0] * (world + 1)
@@ -45,39 +107,33 @@ def exchange_rows(inp, in_sizes, out_sizes, group=None, chunk=A2A_CHUNK):
         in_off[p + 1] = in_off[p] + in_sizes[p]
         out_off[p + 1] = out_off[p] + out_sizes[p]
     out = torch.empty((out_off[world],), dtype=inp.dtype, device=dev)
-    out[out_off[rank]:out_off[rank + 1]] = inp[in_off[rank]:in_off[rank + 1]]
-    peers = [p for p in range(world) if p != rank]
-    most = max([max(in_sizes[p], out_sizes[p]) for p in peers], default=0)
-    r = torch.tensor([(most + chunk - 1) // chunk], dtype=torch.int64, device="cpu" if gloo else dev)
+    most = max([max(in_sizes[p], out_sizes[p]) for p in range(world)], default=0)
+    r = torch.tensor([(most + chunk - 1) // chunk], dtype=torch.int64, device="cpu" if comm.gloo else dev)
     if world > 1:
-        dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
-    for t in range(int(r.item())):
-        ss = [0 if p == rank else max(0, min(chunk, in_sizes[p] - t * chunk)) for p in range(world)]
-        rs = [0 if p == rank else max(0, min(chunk, out_sizes[p] - t * chunk)) for p in range(world)]
-        send = torch.cat([inp[in_off[p] + t * chunk: in_off[p] + t * chunk + ss[p]] for p in range(world)])
-        recv = torch.empty((sum(rs),), dtype=inp.dtype, device="cpu" if gloo else dev)
-        dist.all_to_all_single(recv, send.cpu() if gloo else send, output_split_sizes=rs, input_split_sizes=ss,
-                               group=group)
-        at = 0
-        for p in range(world):
-            if rs[p]:
-                out[out_off[p] + t * chunk: out_off[p] + t * chunk + rs[p]] = recv[at:at + rs[p]].to(dev)
-                at += rs[p]
+        comm.all_reduce(r, "max")
+    rounds = int(r.item())
+    if rounds <= 1:
+        comm.all_to_all(out, inp, list(out_sizes), list(in_sizes))   # no staging copy on either side
+    else:
+        out[out_off[rank]:out_off[rank + 1]] = inp[in_off[rank]:in_off[rank + 1]]
+        for t in range(rounds):
+            ss = [0 if p == rank else max(0, min(chunk, in_sizes[p] - t * chunk)) for p in range(world)]
+            rs = [0 if p == rank else max(0, min(chunk, out_sizes[p] - t * chunk)) for p in range(world)]
+            send = torch.cat([inp[in_off[p] + t * chunk: in_off[p] + t * chunk + ss[p]] for p in range(world)])
+            recv = torch.empty((sum(rs),), dtype=inp.dtype, device=dev)
+            comm.all_to_all(recv, send, rs, ss)
+            at = 0
+            for p in range(world):
+                if rs[p]:
+                    out[out_off[p] + t * chunk: out_off[p] + t * chunk + rs[p]] = recv[at:at + rs[p]]
+                    at += rs[p]
     # integrity: checksums of what was meant for each peer vs what arrived from each peer
     mine = torch.stack([inp[in_off[p]:in_off[p + 1]].sum() for p in range(world)]).to(torch.int64)
     theirs = torch.empty_like(mine)
-    if gloo:
-        t_cpu = torch.empty((world,), dtype=torch.int64)
-        dist.all_to_all_single(t_cpu, mine.cpu(), group=group)
-        theirs = t_cpu.to(dev)
-    else:
-        dist.all_to_all_single(theirs, mine, group=group)
+    comm.all_to_all(theirs, mine)
     got = torch.stack([out[out_off[p]:out_off[p + 1]].sum() for p in range(world)]).to(torch.int64)
     bad = [p for p in range(world) if int(got[p]) != int(theirs[p])]
-    ok = torch.tensor([0 if bad else 1], dtype=torch.int64, device="cpu" if gloo else dev)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)  # every rank fails together, nobody hangs
-    if int(ok.item()) == 0:
+    if not agree(not bad, comm, dev):   # every rank fails together, nobody hangs
         raise RuntimeError("all-to-all payload corrupted in transit (rank %d: checksum mismatch from ranks %s)"
                            % (rank, bad))
     return out
@@ -91,46 +147,50 @@ def exchange_segments(kmers, counts, seg_counts, group=None):
     seg_counts [world] int64 -- rows destined to each rank
     Returns (recv_kmers, recv_counts) with everything this rank owns.
     """
-    world = dist.get_world_size(group)
+    comm = _comm(group)
+    world = comm.world
     wk = kmers.shape[1]
-    gloo = dist.get_backend(group) == "gloo"
     send_sizes = seg_counts.to(torch.int64).contiguous()
     recv_sizes = torch.empty_like(send_sizes)
-    if gloo and send_sizes.is_cuda:
-        r_cpu = torch.empty((world,), dtype=torch.int64)
-        dist.all_to_all_single(r_cpu, send_sizes.cpu(), group=group)
-        recv_sizes = r_cpu
-    else:
-        dist.all_to_all_single(recv_sizes, send_sizes, group=group)
+    comm.all_to_all(recv_sizes, send_sizes)
     ss = [int(x) for x in send_sizes.tolist()]
     rs = [int(x) for x in recv_sizes.tolist()]
     assert len(ss) == world and sum(ss) == kmers.shape[0]
-    recv_k = exchange_rows(kmers.contiguous().view(-1), [x * wk for x in ss], [x * wk for x in rs], group).view(-1, wk)
-    recv_c = exchange_rows(counts.contiguous(), ss, rs, group)
+    recv_k = exchange_rows(kmers.contiguous().view(-1), [x * wk for x in ss], [x * wk for x in rs], comm).view(-1, wk)
+    recv_c = exchange_rows(counts.contiguous(), ss, rs, comm)
     return recv_k, recv_c
 
 
 def merge_tables(hmap, group=None):
     """Merge the per-GPU tables in place (see module docstring).  Returns the
     number of entries this rank received."""
-    from . import _check
-    world = dist.get_world_size(group)
+    from . import OK, TSXException, _check
+    comm = _comm(group)
+    world = comm.world
     dev = torch.device("cuda", hmap.device)
     n = hmap.stats()["distinct"]
     kmers = torch.empty((max(n, 1), hmap.wk), dtype=torch.int64, device=dev)
     counts = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
     seg = torch.zeros((world,), dtype=torch.int64, device=dev)
     torch.cuda.synchronize(dev)
-    _check(hmap._lib.tsx_hip_partition_device(hmap.handle, world, ctypes.c_void_p(kmers.data_ptr()),
-                                              ctypes.c_void_p(counts.data_ptr()), max(n, 1),
-                                              ctypes.c_void_p(seg.data_ptr()), None))
-    recv_k, recv_c = exchange_segments(kmers[:n], counts[:n], seg, group)
+    rc = hmap._lib.tsx_hip_partition_device(hmap.handle, world, ctypes.c_void_p(kmers.data_ptr()),
+                                            ctypes.c_void_p(counts.data_ptr()), max(n, 1),
+                                            ctypes.c_void_p(seg.data_ptr()), None)
+    if not agree(rc == OK, comm, dev):
+        _check(rc)
+        raise TSXException(rc, "merge_tables: another rank failed to group its table by owner")
+    recv_k, recv_c = exchange_segments(kmers[:n], counts[:n], seg, comm)
     torch.cuda.synchronize(dev)
     hmap.clear()
+    rc = OK
     if recv_k.shape[0]:
-        _check(hmap._lib.tsx_hip_add_kmers_device(hmap.handle, ctypes.c_void_p(recv_k.data_ptr()),
-                                                  ctypes.c_void_p(recv_c.data_ptr()), recv_k.shape[0], None))
-    hmap.sync()
+        rc = hmap._lib.tsx_hip_add_kmers_device(hmap.handle, ctypes.c_void_p(recv_k.data_ptr()),
+                                                ctypes.c_void_p(recv_c.data_ptr()), recv_k.shape[0], None)
+    if rc == OK:
+        rc = hmap._lib.tsx_hip_sync(hmap.handle)
+    if not agree(rc == OK, comm, dev):
+        _check(rc)
+        raise TSXException(rc, "merge_tables: another rank failed to insert what it received")
     return int(recv_k.shape[0])
 
 
@@ -138,81 +198,162 @@ class ShardedCounter:
     """Multi-GPU counting into ONE table sharded by slot range (k <= 32).
 
     Rank r holds home slots [r << l, (r+1) << l) of a table with 2^(l + log2 world)
-    slots (TSXHashMapHIP(..., shard_bits=log2 world, shard_index=r)).  Every rank
-    scans its own reads; the hashed keys travel to their owners through ONE
-    all-to-all BEFORE they are built into a table, so nothing is inserted twice and
-    no table is torn down and re-inserted (merge_tables() does that).  Hot k-mers
-    that the scan merged on chip travel as a small (key, count) list through an
-    all-gather.  After step() rank r answers getKmerCount for the k-mers it owns.
+    slots (TSXHashMapHIP(..., shard_bits=log2 world, shard_index=r)).  step() counts one
+    device text of this rank's reads:
+
+        compute stream   scan(0) scan(1) build(0) scan(2) build(1) ... build(W-1)
+        exchange stream        sizes(0) a2a(0)  sizes(1) a2a(1) ...
+
+    scan(i)   tsx_hip_shard_scan_window_device: window i of the text -> keys grouped by owner
+              (own keys straight into the receive buffer), per-owner counts, hot (key, count) list
+    sizes(i)  ONE small all-to-all carries, per pair: keys to come, this rank's status, the
+              length of its hot list.  Its result is the only thing the host waits for, and it
+              waits while scan(i+1) is already queued on the GPU
+    a2a(i)    ONE all_to_all_single with split sizes, from the send buffer into the receive buffer
+              behind the own keys; hot lists by all-gather (owners pick theirs)
+    build(i)  tsx_hip_shard_build_device + tsx_hip_add_hashed_device
+
+    Two send / receive / hot buffers alternate.  Integrity: every scan adds the sum of the keys it
+    wrote, every build the sum of the keys it read; the two totals must agree over all ranks
+    (one all-reduce per step).  After step() rank r answers getKmerCount for the k-mers it owns.
     """
 
-    HOT_CAP = 1 << 20
+    HOT_CAP = 1 << 18
+    MIN_WINDOW = 32 << 20      # bytes of text below which a step is not split further
 
-    def __init__(self, hmap, max_text_bytes, group=None):
+    def __init__(self, hmap, max_text_bytes, group=None, windows=None):
         from . import _check
-        self.m, self.group = hmap, group
-        self.world = dist.get_world_size(group)
+        self.m = hmap
+        self.comm = _comm(group)
+        self.world, self.rank = self.comm.world, self.comm.rank
         assert self.world == 1 << hmap.layout.shard_bits, "world size must equal 2^shard_bits"
         self.dev = torch.device("cuda", hmap.device)
+        if windows is None:
+            windows = int(os.environ.get("TSX_HIP_SHARD_WINDOWS", "0")) or max(1, min(4, max_text_bytes // self.MIN_WINDOW))
+        self.windows = max(1, int(windows))
+        self.win_bytes = max(4096, ((max_text_bytes + self.windows - 1) // self.windows + 4095) & ~4095)
         cap = ctypes.c_size_t(0)
-        _check(hmap._lib.tsx_hip_shard_send_capacity(hmap.handle, max_text_bytes, ctypes.byref(cap)))
-        self.send = torch.empty((cap.value,), dtype=torch.int64, device=self.dev)
-        self.counts = torch.zeros((self.world,), dtype=torch.int64, device=self.dev)
-        self.hot_k = torch.zeros((self.HOT_CAP,), dtype=torch.int64, device=self.dev)
-        self.hot_c = torch.zeros((self.HOT_CAP,), dtype=torch.int64, device=self.dev)
-        self.hot_n = torch.zeros((1,), dtype=torch.int64, device=self.dev)
-        self.recv = torch.empty((0,), dtype=torch.int64, device=self.dev)
-        self.gloo = dist.get_backend(group) == "gloo"
+        _check(hmap._lib.tsx_hip_shard_send_capacity(hmap.handle, self.win_bytes + 256, ctypes.byref(cap)))
+        self.send_cap = cap.value
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        self.send = [torch.empty((self.send_cap,), **i64) for _ in range(2)]
+        # receive buffer: own keys in front (any number up to the window's total), the peers' behind
+        self.recv = [torch.empty((2 * self.send_cap,), **i64) for _ in range(2)]
+        self.counts = [torch.zeros((self.world,), **i64) for _ in range(2)]
+        self.hot_k = [torch.zeros((self.HOT_CAP,), **i64) for _ in range(2)]
+        self.hot_c = [torch.zeros((self.HOT_CAP,), **i64) for _ in range(2)]
+        self.hot_n = [torch.zeros((1,), **i64) for _ in range(2)]
+        self.hot_all_k = [torch.zeros((0,), **i64) for _ in range(2)]
+        self.hot_all_c = [torch.zeros((0,), **i64) for _ in range(2)]
+        self.sums = torch.zeros((2,), **i64)      # [0] += keys written by the scans, [1] += keys read by the builds
+        self.cs = torch.cuda.Stream(self.dev)     # every kernel of a step
+        self.xs = torch.cuda.Stream(self.dev)     # the collectives
+        self.ev_scan = [torch.cuda.Event() for _ in range(2)]
+        self.ev_exch = [torch.cuda.Event() for _ in range(2)]
+        self.last = {}
 
-    def _a2a(self, out, inp, out_sizes=None, in_sizes=None):
-        if self.gloo:  # CPU collective (tests: several ranks sharing one GPU)
-            o = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_sizes, input_split_sizes=in_sizes,
-                                   group=self.group)
-            out.copy_(o)
-        else:
-            dist.all_to_all_single(out, inp, output_split_sizes=out_sizes, input_split_sizes=in_sizes,
-                                   group=self.group)
+    def _scan(self, i, text_ptr, nbytes):
+        m, L, vp, b = self.m, self.m._lib, ctypes.c_void_p, i & 1
+        off = i * self.win_bytes
+        ln = max(0, min(self.win_bytes, nbytes - off))
+        rc = L.tsx_hip_shard_scan_window_device(
+            m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln, vp(self.send[b].data_ptr()), self.send_cap,
+            vp(self.recv[b].data_ptr()), self.recv[b].numel(), vp(self.counts[b].data_ptr()),
+            vp(self.hot_k[b].data_ptr()), vp(self.hot_c[b].data_ptr()), self.HOT_CAP, vp(self.hot_n[b].data_ptr()),
+            vp(self.sums.data_ptr()), vp(self.cs.cuda_stream))
+        self.ev_scan[b].record(self.cs)
+        return rc
 
     def step(self, text_ptr, nbytes):
-        """Count one FASTQ text (device pointer) of this rank's reads into the sharded table."""
-        from . import _check
-        m, L = self.m, self.m._lib
-        vp = ctypes.c_void_p
-        _check(L.tsx_hip_shard_scan_device(m.handle, vp(text_ptr), nbytes, vp(self.send.data_ptr()),
-                                           self.send.numel(), vp(self.counts.data_ptr()), vp(self.hot_k.data_ptr()),
-                                           vp(self.hot_c.data_ptr()), self.HOT_CAP, vp(self.hot_n.data_ptr()), None))
-        torch.cuda.synchronize(self.dev)
-        ss = [int(x) for x in self.counts.tolist()]
-        recv_sizes = torch.empty_like(self.counts)
-        self._a2a(recv_sizes, self.counts)
-        rs = [int(x) for x in recv_sizes.tolist()]
-        n_recv = sum(rs)
-        self.recv = exchange_rows(self.send[:sum(ss)], ss, rs, self.group)
-        # hot (key, count) lists: pad to the longest, gather everywhere, owners pick theirs
-        nh = torch.tensor([min(int(self.hot_n.item()), self.HOT_CAP)], dtype=torch.int64,
-                          device="cpu" if self.gloo else self.dev)
-        dist.all_reduce(nh, op=dist.ReduceOp.MAX, group=self.group)
-        nh = int(nh.item())
-        hk = hc = None
-        if nh:
-            mine = min(int(self.hot_n.item()), self.HOT_CAP)
-            self.hot_c[mine:nh].zero_()   # entries past this rank's own list carry count 0 = ignored
-            src_k, src_c = self.hot_k[:nh], self.hot_c[:nh]
-            if self.gloo:
-                gk = [torch.empty((nh,), dtype=torch.int64) for _ in range(self.world)]
-                gc = [torch.empty((nh,), dtype=torch.int64) for _ in range(self.world)]
-                dist.all_gather(gk, src_k.cpu(), group=self.group)
-                dist.all_gather(gc, src_c.cpu(), group=self.group)
-                hk, hc = torch.cat(gk).to(self.dev), torch.cat(gc).to(self.dev)
+        """Count one FASTQ text (device pointer, 16-byte aligned) of this rank's reads into the sharded table."""
+        from . import OK, TSXException, _check
+        m, L, vp = self.m, self.m._lib, ctypes.c_void_p
+        world, rank, comm = self.world, self.rank, self.comm
+        nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
+        # the caller's text may have been produced on another stream
+        self.cs.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.cs):
+            self.sums.zero_()
+        n_recv_total = 0
+        failure = None
+        rc_scan = self._scan(0, text_ptr, nbytes)
+        for i in range(nwin):
+            b = i & 1
+            rc_this = rc_scan
+            if i + 1 < nwin and failure is None:
+                rc_scan = self._scan(i + 1, text_ptr, nbytes)   # queued before the host waits for window i
+            with torch.cuda.stream(self.xs):
+                self.xs.wait_event(self.ev_scan[b])
+                # sizes(i): row p = [keys for p, my status, my hot keys]
+                meta_in = torch.empty((world, 3), dtype=torch.int64, device=self.dev)
+                meta_in[:, 0] = self.counts[b]
+                meta_in[:, 1] = int(rc_this)
+                meta_in[:, 2] = self.hot_n[b]
+                meta_out = torch.empty_like(meta_in)
+                comm.all_to_all(meta_out, meta_in)
+                host = torch.cat([meta_out.view(-1), self.counts[b], self.hot_n[b]]).cpu()   # the one host wait
+                mo = host[:3 * world].view(world, 3)
+                mine = [int(x) for x in host[3 * world:4 * world].tolist()]
+                my_hot = min(int(host[4 * world]), self.HOT_CAP)
+                status = [int(x) for x in mo[:, 1].tolist()]
+                if any(s != OK for s in status):
+                    failure = (i, status)
+                    break
+                own = mine[rank]
+                ss = [0 if p == rank else mine[p] for p in range(world)]
+                rs = [0 if p == rank else int(mo[p, 0]) for p in range(world)]
+                n_recv = own + sum(rs)
+                if n_recv > self.recv[b].numel():   # skewed ownership: grow, keeping the own keys already there
+                    bigger = torch.empty((n_recv + n_recv // 4,), dtype=torch.int64, device=self.dev)
+                    bigger[:own] = self.recv[b][:own]
+                    self.xs.synchronize()
+                    self.recv[b] = bigger
+                if world > 1:
+                    comm.all_to_all(self.recv[b][own:n_recv], self.send[b][:sum(ss)], rs, ss)
+                # hot lists: padded to the longest, gathered everywhere, owners pick theirs
+                nh = max(int(x) for x in mo[:, 2].tolist())
+                nh = min(max(nh, 0), self.HOT_CAP)
+                g = 0
+                if nh:
+                    g = 1 << (nh - 1).bit_length()
+                    self.hot_c[b][my_hot:g].zero_()   # entries past this rank's own list carry count 0 = ignored
+                    if self.hot_all_k[b].numel() < g * world:
+                        self.hot_all_k[b] = torch.empty((g * world,), dtype=torch.int64, device=self.dev)
+                        self.hot_all_c[b] = torch.empty((g * world,), dtype=torch.int64, device=self.dev)
+                    comm.all_gather(self.hot_all_k[b][:g * world], self.hot_k[b][:g])
+                    comm.all_gather(self.hot_all_c[b][:g * world], self.hot_c[b][:g])
+                self.ev_exch[b].record(self.xs)
+            self.cs.wait_event(self.ev_exch[b])
+            rc = L.tsx_hip_shard_build_device(m.handle, vp(self.recv[b].data_ptr()), n_recv, vp(self.sums[1:].data_ptr()),
+                                              vp(self.cs.cuda_stream))
+            if rc == OK and g:
+                rc = L.tsx_hip_add_hashed_device(m.handle, vp(self.hot_all_k[b].data_ptr()),
+                                                 vp(self.hot_all_c[b].data_ptr()), g * world, vp(self.cs.cuda_stream))
+            if rc != OK:
+                # the next sizes exchange carries it to the peers; in the last window the final agreement does
+                rc_scan = rc if i + 1 < nwin else rc_scan
+                failure_local = rc
             else:
-                hk = torch.empty((nh * self.world,), dtype=torch.int64, device=self.dev)
-                hc = torch.empty((nh * self.world,), dtype=torch.int64, device=self.dev)
-                dist.all_gather_into_tensor(hk, src_k.contiguous(), group=self.group)
-                dist.all_gather_into_tensor(hc, src_c.contiguous(), group=self.group)
-        torch.cuda.synchronize(self.dev)
-        _check(L.tsx_hip_shard_build_device(m.handle, vp(self.recv.data_ptr()), n_recv, None))
-        if nh:
-            _check(L.tsx_hip_add_hashed_device(m.handle, vp(hk.data_ptr()), vp(hc.data_ptr()), hk.numel(), None))
+                failure_local = OK
+            n_recv_total += n_recv
+            if failure_local != OK and i + 1 >= nwin:
+                failure = (i, [failure_local])
+        self.cs.synchronize()
+        self.xs.synchronize()
+        # integrity of the exchange + agreement on failures: one small all-reduce per step
+        fin = torch.stack([self.sums[0] - self.sums[1],
+                           torch.tensor(0 if failure is None else 1, dtype=torch.int64, device=self.dev)])
+        red = fin.cpu() if comm.gloo else fin
+        comm.all_reduce(red, "sum") if world > 1 else None
+        diff, nfail = int(red[0].item()), int(red[1].item())
+        self.last = {"windows": nwin, "received_keys": n_recv_total, "key_sum_diff": diff}
+        if nfail:
+            if failure is not None:
+                bad = [s for s in failure[1] if s != OK]
+                _check(bad[0])
+            raise TSXException(-4, "sharded step: another rank failed")
+        if diff != 0:
+            raise RuntimeError("sharded step: keys lost or corrupted in the exchange (sum of keys scanned - built, "
+                               "over all ranks = %d)" % diff)
         m.sync()
-        return n_recv
+        return n_recv_total
