@@ -174,6 +174,14 @@ int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uin
 int tsx_hip_get_counts_device(tsx_hip_map *m, const void *dev_kmers, size_t n, void *dev_counts_out,
                               void *stream);
 
+/* getKmerCountDebug(kmer) (TSXHashMap.h:477-545): the count AND the slot the k-mer sits in
+ * (KmerCountDebug::iFirstPos; UINT64_MAX when absent) -- main.cpp's --check marks these slots. */
+int tsx_hip_lookup_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out,
+                        uint64_t *slots_out);
+/* getKmerStarts / getKmerStartsRef (TSXHashMap.h:650-658) as a bitmap of 2^l bits: bit (i & 7) of
+ * byte (i >> 3) is set iff slot i holds a k-mer.  nbytes >= 2^l / 8. */
+int tsx_hip_kmer_starts_host(tsx_hip_map *m, uint8_t *bits_out, size_t nbytes);
+
 /* getKmerCount() / print_stats() / iAddKmerCount (TSXHashMap.h:645,390; main.cpp:486-500). */
 int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out);
 

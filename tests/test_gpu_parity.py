@@ -115,6 +115,52 @@ def test_reference_binary_checks_hip_counts(T, tmp_path):
     m.close()
 
 
+def test_reference_main_with_hip_subclass_check_passes(T, tmp_path):
+    """The reference's OWN main.cpp -- its FASTXreader, createKMers, TSXSeqUtils::fromSequence, its
+    countKMers loop and its --check loop (main.cpp:104-396) -- compiled where it lies with --mode=HIP added
+    (oracle/ref_hip_mode.sed) and `class TSXHashMapHIP : public TSXHashMap`
+    (tsxcount_amd/host/ref_binding/TSXHashMapHIP.h) over the C ABI: every addKmer / getKmerCount(kmer) /
+    getKmerCountDebug goes through the virtual interface into the HIP table.  'total errors0' is printed by
+    the reference's code, against the reference's own golden .count file."""
+    import re
+    exe = os.path.join(ROOT, "oracle", "_ref", "tsxCount_ref_hip")
+    if not os.path.exists(exe):
+        pytest.skip("reference-linked binary not built (oracle/Makefile needs /root/reference)")
+    fq = tmp_path / "small_t7.1000.fastq"
+    fq.write_bytes(open(os.path.join(GOLDEN, "small_t7.1000.fastq"), "rb").read())
+    with gzip.open(os.path.join(GOLDEN, "small_t7.1000.fastq.14.count.gz"), "rb") as f:
+        (tmp_path / "small_t7.1000.fastq.14.count").write_bytes(f.read())
+    p = subprocess.run([exe, "--input=%s" % fq, "--k=14", "--l=20", "--s=4", "--mode=HIP", "--threads=2", "--check"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-2000:] + p.stderr.decode(errors="replace")[-2000:]
+    assert "Creating TSXHashMap HIP" in p.stderr.decode(errors="replace")
+    assert "Added a total of 194697 different kmers" in out
+    assert int(re.search(r"total errors(\d+)", out).group(1)) == 0
+    assert "Reference kmer count: 194697" in out
+    assert "tsxCount kmer count: 194697" in out
+    # every slot the check visited is a k-mer start and vice versa (main.cpp:381-388)
+    assert "queried kmer count: 194697" in out and "queried (Xor) kmer count: 0" in out
+
+
+def test_lookup_with_slot_and_kmer_starts(T):
+    """getKmerCountDebug (TSXHashMap.h:477-545) and getKmerStarts (:650-658) over the C ABI."""
+    from tsxcount_amd import synth
+    text = synth.fastq(21, 0, 30)
+    m = T.TSXHashMapHIP(16, 0, 31)
+    m.countFastq(text)
+    kmers, counts = m.getAllKmers()
+    got, slots = m.getKmerCountDebug(kmers)
+    assert np.array_equal(got, counts)
+    starts = m.getKmerStarts()
+    assert starts.sum() == len(kmers) == m.stats()["distinct"]
+    assert len(np.unique(slots)) == len(kmers) and starts[slots.astype(np.int64)].all()
+    absent = T.encode("ACGT" * 7 + "ACG")
+    c, sl = m.getKmerCountDebug(absent)
+    assert int(c[0]) == 0 and int(sl[0]) == 2 ** 64 - 1
+    m.close()
+
+
 # --- oracle parity over k, table geometry and slot width ------------------------------
 
 @pytest.mark.parametrize("k,l,s,reads", [

@@ -90,6 +90,8 @@ def lib():
     L.tsx_hip_add_kmers_device.argtypes = [vp, vp, vp, sz, vp]
     L.tsx_hip_get_counts_host.argtypes = [vp, u64p, sz, u64p]
     L.tsx_hip_get_counts_device.argtypes = [vp, vp, sz, vp, vp]
+    L.tsx_hip_lookup_host.argtypes = [vp, u64p, sz, u64p, u64p]
+    L.tsx_hip_kmer_starts_host.argtypes = [vp, ctypes.POINTER(ctypes.c_uint8), sz]
     L.tsx_hip_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.tsx_hip_dump_host.argtypes = [vp, u64p, u64p, sz, ctypes.POINTER(sz)]
     L.tsx_hip_dump_device.argtypes = [vp, vp, vp, sz, vp, vp]
@@ -218,6 +220,21 @@ class TSXHashMapHIP:
         out = np.zeros(a.shape[0], dtype=np.uint64)
         _check(self._lib.tsx_hip_get_counts_host(self._h, _p(a), a.shape[0], _p(out)))
         return out
+
+    def getKmerCountDebug(self, kmers):
+        """getKmerCountDebug (TSXHashMap.h:477): (counts, slots); slot = 2^64-1 for absent k-mers."""
+        a = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1, self.wk)
+        out = np.zeros(a.shape[0], dtype=np.uint64)
+        pos = np.zeros(a.shape[0], dtype=np.uint64)
+        _check(self._lib.tsx_hip_lookup_host(self._h, _p(a), a.shape[0], _p(out), _p(pos)))
+        return out, pos
+
+    def getKmerStarts(self):
+        """getKmerStarts (TSXHashMap.h:650) as a numpy bool array over the 2^l slots."""
+        nb = (int(self.layout.slots) + 7) // 8
+        bits = np.zeros(nb, dtype=np.uint8)
+        _check(self._lib.tsx_hip_kmer_starts_host(self._h, bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), nb))
+        return np.unpackbits(bits, bitorder="little")[:int(self.layout.slots)].astype(bool)
 
     def getAllKmers(self):
         """TSXHashMap::getAllKmers (TSXHashMap.h:660) with counts; order unspecified."""

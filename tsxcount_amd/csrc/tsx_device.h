@@ -229,8 +229,11 @@ __device__ inline bool insert_key(const TableParams &p, const uint64_t (&h)[WK],
 
 // getKmerCount(kmer) (TSXHashMap.h:548-638).  Plain loads: runs in its own
 // launch after every insert kernel has finished.
+// pos_out (optional): the slot the k-mer was found in, ~0 when it is not in the table
+// (KmerCountDebug::iFirstPos of getKmerCountDebug, TSXHashMap.h:477-545).
 template <int WK>
-__device__ inline uint64_t lookup_key(const TableParams &p, const uint64_t (&h)[WK]) {
+__device__ inline uint64_t lookup_key(const TableParams &p, const uint64_t (&h)[WK], uint64_t *pos_out = nullptr) {
+    if (pos_out) *pos_out = ~0ULL;
     if (p.lg != p.l && owner_shard<WK>(p, h) != p.shard) return 0;  // lives on another GPU
     uint64_t pos0, e0, hi[4];
     split_key<WK>(p, h, pos0, e0, hi);
@@ -244,6 +247,7 @@ __device__ inline uint64_t lookup_key(const TableParams &p, const uint64_t (&h)[
         bool same = true;
         for (int t = 1; t < W; ++t) same &= (e[t] == hi[t - 1]);
         if (!same) continue;
+        if (pos_out) *pos_out = pos;
         return (v >> p.cshift) + (sec_get(p, pos) << p.C);
     }
     return 0;

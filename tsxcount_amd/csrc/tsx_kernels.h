@@ -616,14 +616,27 @@ __global__ __launch_bounds__(NT) void add_kmers_kernel(TableParams p, const uint
 
 template <int WK>
 __global__ __launch_bounds__(NT) void get_counts_kernel(TableParams p, const uint64_t *kmers, uint64_t n,
-                                                        uint64_t *out) {
+                                                        uint64_t *out, uint64_t *pos_out) {
     for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * NT) {
         uint64_t x[WK], h[WK];
 #pragma unroll
         for (int t = 0; t < WK; ++t) x[t] = kmers[i * WK + t];
         x[WK - 1] &= p.top_mask;
         hash_apply<WK>(p, p.lut, x, h);
-        out[i] = lookup_key<WK>(p, h);
+        out[i] = lookup_key<WK>(p, h, pos_out ? pos_out + i : nullptr);
+    }
+}
+
+// getKmerStarts (TSXHashMap.h:650-658) as a bitmap: bit (i & 7) of byte (i >> 3) = slot i is occupied.
+__global__ __launch_bounds__(NT) void kmer_starts_kernel(TableParams p, uint8_t *bits, uint64_t nbytes) {
+    const uint64_t slots = p.slot_mask + 1;
+    for (uint64_t b = (uint64_t)blockIdx.x * NT + threadIdx.x; b < nbytes; b += (uint64_t)gridDim.x * NT) {
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint64_t i = b * 8 + j;
+            if (i < slots && p.table[i * (uint64_t)p.W] != 0) v |= 1u << j;
+        }
+        bits[b] = (uint8_t)v;
     }
 }
 

@@ -74,6 +74,7 @@ struct tsx_hip_map {
     unsigned long long *d_cnt = nullptr;   // [log regions | level-1 lists | segment lists]
     size_t cnt_entries = 0;
     // optional per-pass timing (HIP events on the launch stream)
+    uint64_t *d_small = nullptr;     // scratch of tsx_hip_get_counts_host / tsx_hip_lookup_host for a few k-mers
     bool attr_done = false;          // dynamic-LDS limits of the partition / build kernels set on this map's device
     int timing = 0;
     int dbg = 0;                     // TSX_HIP_DEBUG: bit0 = skip the global insert (ablation builds only)
@@ -404,7 +405,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
-    (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt);
+    (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt); (void)hipFree(m->d_small);
     (void)hipFree(m->d_tile); (void)hipFree(m->d_carry); (void)hipFree(m->d_seg);
     (void)hipFree(m->p.seg_dirty); (void)hipFree(m->d_buf[0]); (void)hipFree(m->d_buf[1]); (void)hipFree(m->d_cnt);
     for (int i = 0; i < 2; ++i) {
@@ -1012,30 +1013,68 @@ extern "C" int tsx_hip_get_counts_device(tsx_hip_map *m, const void *dev_kmers, 
     hipStream_t st = pick_stream(m, stream);
     const int grid = grid_for(m, n, 8);
     DISPATCH_WK(m, hipLaunchKernelGGL((get_counts_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p,
-                                      (const uint64_t *)dev_kmers, (uint64_t)n, (uint64_t *)dev_counts_out));
+                                      (const uint64_t *)dev_kmers, (uint64_t)n, (uint64_t *)dev_counts_out,
+                                      (uint64_t *)nullptr));
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out) {
+// Host-side lookups of a handful of k-mers (the reference calls getKmerCount one k-mer at a time,
+// main.cpp:285-330) go through a small device scratch kept with the map instead of hipMalloc/hipFree.
+static const size_t SMALL_LOOKUP = 256;
+static int lookup_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out, uint64_t *slots_out) {
     if (!m || ((!kmers || !counts_out) && n)) return TSX_HIP_EINVAL;
     if (n == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
-    uint64_t *dk = nullptr, *dc = nullptr;
-    const size_t kb = n * (size_t)m->p.wk * 8;
-    HIP_TRY(hipMalloc((void **)&dk, kb));
-    if (hipMalloc((void **)&dc, n * 8) != hipSuccess) { (void)hipFree(dk); return TSX_HIP_ENOMEM; }
+    const size_t wk = (size_t)m->p.wk, kb = n * wk * 8;
+    uint64_t *dk = nullptr, *dc = nullptr, *dp = nullptr;
+    const bool small = n <= SMALL_LOOKUP;
+    if (small) {
+        if (!m->d_small) HIP_TRY(hipMalloc((void **)&m->d_small, SMALL_LOOKUP * (4 + 2) * 8));
+        dk = m->d_small; dc = dk + SMALL_LOOKUP * 4; dp = dc + SMALL_LOOKUP;
+    } else {
+        HIP_TRY(hipMalloc((void **)&dk, kb));
+        if (hipMalloc((void **)&dc, n * 16) != hipSuccess) { (void)hipFree(dk); return TSX_HIP_ENOMEM; }
+        dp = dc + n;
+    }
     int rc = TSX_HIP_OK;
     do {
         if (hipMemcpyAsync(dk, kmers, kb, hipMemcpyHostToDevice, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
-        rc = tsx_hip_get_counts_device(m, dk, n, dc, nullptr);
-        if (rc != TSX_HIP_OK) break;
+        const int grid = grid_for(m, n, 8);
+        DISPATCH_WK(m, hipLaunchKernelGGL((get_counts_kernel<WKV>), dim3(grid), dim3(NT), 0, m->stream, m->p,
+                                          (const uint64_t *)dk, (uint64_t)n, dc, slots_out ? dp : (uint64_t *)nullptr));
+        if (hipGetLastError() != hipSuccess) { rc = TSX_HIP_EHIP; break; }
         if (hipMemcpyAsync(counts_out, dc, n * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        if (slots_out && hipMemcpyAsync(slots_out, dp, n * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
         if (hipStreamSynchronize(m->stream) != hipSuccess) rc = TSX_HIP_EHIP;
     } while (0);
-    (void)hipStreamSynchronize(m->stream);
-    (void)hipFree(dk); (void)hipFree(dc);
+    if (!small) { (void)hipStreamSynchronize(m->stream); (void)hipFree(dk); (void)hipFree(dc); }
     return rc;
+}
+
+extern "C" int tsx_hip_lookup_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out,
+                                   uint64_t *slots_out) {
+    if (!slots_out && n) return TSX_HIP_EINVAL;
+    return lookup_host(m, kmers, n, counts_out, slots_out);
+}
+
+extern "C" int tsx_hip_kmer_starts_host(tsx_hip_map *m, uint8_t *bits_out, size_t nbytes) {
+    if (!m || !bits_out || nbytes * 8 < m->lay.slots) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    const uint64_t nb = (m->lay.slots + 7) / 8;
+    uint8_t *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, nb));
+    hipLaunchKernelGGL(kmer_starts_kernel, dim3(grid_for(m, nb, 8)), dim3(NT), 0, m->stream, m->p, d, nb);
+    int rc = (hipGetLastError() == hipSuccess &&
+              hipMemcpyAsync(bits_out, d, nb, hipMemcpyDeviceToHost, m->stream) == hipSuccess &&
+              hipStreamSynchronize(m->stream) == hipSuccess) ? TSX_HIP_OK : TSX_HIP_EHIP;
+    (void)hipFree(d);
+    if (rc == TSX_HIP_OK && nbytes > nb) memset(bits_out + nb, 0, nbytes - nb);
+    return rc;
+}
+
+extern "C" int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out) {
+    return lookup_host(m, kmers, n, counts_out, nullptr);
 }
 
 extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
