@@ -288,23 +288,28 @@ def main():
         # text and writes one 8-byte key per logged k-mer (atomic path: reads the text, reads + writes one
         # slot per k-mer); a radix level reads and writes every key once; the build reads every key once
         # and writes every slot of the table once.
-        table_bytes = 8.0 * (1 << args.l)
-        stage_bytes = {"scan": nbytes + (8.0 * keys_logged if partitioned else 16.0 * kmers_rank),
-                       "level1": 16.0 * keys_logged, "level2": 16.0 * keys_logged,
-                       "build": 8.0 * keys_logged + table_bytes}
-        names = {"scan": "scan_log_kernel" if partitioned else "count_fastq_kernel<1>",
+        # a logged record is 1, 2 or 4 words (3-limb keys travel as 4), a slot entry_limbs words
+        rec_b = 8.0 * {1: 1, 2: 2, 3: 4, 4: 4}[m.wk]
+        slot_b = 8.0 * m.layout.entry_limbs
+        table_bytes = slot_b * (1 << args.l)
+        stage_bytes = {"scan": nbytes + (rec_b * keys_logged if partitioned else 2 * slot_b * kmers_rank),
+                       "level1": 2 * rec_b * keys_logged, "level2": 2 * rec_b * keys_logged,
+                       "build": rec_b * keys_logged + table_bytes}
+        names = {"scan": ("scan_log_kernel" if m.wk == 1 else "scan_log_wide_kernel<%d>" % m.wk) if partitioned
+                 else "count_fastq_kernel<%d>" % m.wk,
                  "level1": "partition_ring_kernel (level 1)", "level2": "partition_ring_kernel (level 2)",
-                 "build": "build_segments_kernel"}
+                 "build": "build_segments_kernel" if (m.wk == 1 and m.layout.entry_limbs == 1)
+                 else "build_segments_wide_kernel<%d>" % m.wk}
         stage_ms = {k2: stage[k2] / pieces for k2 in names}
         dom = max(stage_ms, key=lambda k2: stage_ms[k2])   # the kernel a step spends most time in
         kern_ms = stage_ms[dom]
         kern_bytes = stage_bytes[dom]
         achieved = kern_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        path_bytes = nbytes + 16.0 * kmers_rank
+        path_bytes = nbytes + 2 * slot_b * kmers_rank
         path_ms = (scan_ms + count_ms + build_ms) / pieces
         traffic = None
         prof = {}
-        pmc = os.path.join(ROOT, "profiles", "round1_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "round2_pmc.json" if args.k == 31 else "round2_pmc_k%d.json" % args.k)
         if os.path.exists(pmc):
             try:
                 prof = json.load(open(pmc))
@@ -313,7 +318,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "k-mers/sec inserted, k=31, 1e9 synthetic k-mers, 1/2/4/8 GPU; --check pass",
+            "metric": "k-mers/sec inserted, k=%d, 1e9 synthetic k-mers, 1/2/4/8 GPU; --check pass" % args.k,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",

@@ -242,9 +242,13 @@ def test_prefix_skew_does_not_exhaust_reprobes(T):
 
 @pytest.mark.parametrize("k,l,s,reads", [
     (31, 15, 0, 15), (31, 16, 0, 40), (31, 18, 0, 150), (31, 20, 4, 400), (31, 23, 0, 1500), (31, 24, 0, 2500),
-    (14, 18, 4, 100), (21, 17, 2, 60), (32, 19, 0, 400), (27, 22, 0, 1000), (31, 31, 0, 2000), (27, 32, 0, 1500)])
+    (14, 18, 4, 100), (21, 17, 2, 60), (32, 19, 0, 400), (27, 22, 0, 1000), (31, 31, 0, 2000), (27, 32, 0, 1500),
+    # multi-limb keys (k > 32): 2-, 3- and 4-limb records and slots; segments of 2^13 / 2^12 slots
+    (33, 18, 0, 150), (33, 30, 0, 300), (47, 18, 6, 150), (63, 18, 0, 150), (63, 23, 0, 2500), (64, 19, 0, 300),
+    (65, 18, 3, 150), (95, 18, 0, 150), (96, 20, 0, 600), (97, 18, 0, 150), (127, 18, 0, 150), (127, 19, 2, 300),
+    (127, 22, 0, 2500), (31, 20, 32, 300)])
 def test_partitioned_path_parity_with_oracle(T, k, l, s, reads):
-    """l = 15..22: one radix level; l >= 23: two levels (l = 31, 32: 512 lists per level).  Same counts as the oracle and
+    """One radix level up to 2^8 segments, two levels above (l = 31, 32 at k <= 32: 512 lists per level).  Same counts as the oracle and
     as the atomic path, also when the same text is counted twice into the table
     (second pass merges into segments that already hold data)."""
     from tsxcount_amd import synth
@@ -355,9 +359,12 @@ def test_partitioned_path_golden_and_skew(T, golden_fastq, golden_counts):
     assert np.array_equal(m.getKmerCounts(kmers), exp)
     assert m.stats()["distinct"] == 194697
     m.close()
-    # Zipf-skewed reads: a few segments receive most keys, lists overflow into the atomic path
+    # Zipf-skewed reads: a few segments receive most keys, lists overflow into the queues and the deferred list
     text = synth.zipf_fastq(7, n_reads=6000, read_len=150, n_templates=300, k=31)
     assert_same_as_oracle(T, text, 31, 18, 0, path="partitioned")
+    text63 = synth.zipf_fastq(7, n_reads=6000, read_len=150, n_templates=300, k=63)
+    assert_same_as_oracle(T, text63, 63, 18, 0, path="partitioned")        # BASELINE config 4 at oracle scale
+    assert_same_as_oracle(T, text63, 63, 22, 3, path="partitioned")        # two radix levels, 3-bit counters
     assert_same_as_oracle(T, text, 31, 18, 2, path="partitioned", overflow_l=17)  # nearly every key carries
     # every read identical: one hot stretch of keys
     one = synth.fastq(3, 0, 1)
@@ -414,6 +421,47 @@ def _fuzz_text(rng):
     if rng.random() < 0.3:
         text = text[:max(0, len(text) - int(rng.integers(1, 40)))]  # cut inside the last record
     return text
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzzed_record_structure_wide_keys(T, seed):
+    """The same ragged texts for k = 33..127: three-word newline masks, hash-recognised homopolymers,
+    2/4-word records in the log, the rings and the LDS segments."""
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(33, 128))
+    text = b"".join(_fuzz_text(rng) for _ in range(int(rng.integers(2, 8))))
+    assert_same_as_oracle(T, text, k, 14, 0, path="partitioned")
+    assert_same_as_oracle(T, text, k, 14, 2, path="partitioned", overflow_l=14)
+
+
+@pytest.mark.parametrize("k", list(range(33, 128)))
+def test_rolling_hash_every_multi_limb_k(T, k):
+    """x -> c*x in GF(2^2k) for every multi-limb k (irreducible polynomials of degree 66..254,
+    scripts/find_irreducible.py): the scan rolls the hash from window to window, lookups use the LUT; a
+    wrong polynomial or roll table loses k-mers.  Ragged short reads, homopolymer reads included."""
+    rng = np.random.default_rng(3000 + k)
+    recs = []
+    for r in range(120):
+        n = int(rng.integers(1, 2 * k + 40))
+        if r % 10 == 9:
+            seq = bytes([int(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8)))]) * n
+        else:
+            seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n))
+        recs.append(b"@r%d\n" % r + seq + b"\n+\n" + b"I" * n + b"\n")
+    text = b"".join(recs)
+    exp = python_counts(text, k)
+    kmers = T.encode_many(list(exp.keys()), k) if exp else np.zeros((0, T.key_limbs(k)), dtype=np.uint64)
+    want = np.array(list(exp.values()), dtype=np.uint64)
+    m = T.TSXHashMapHIP(14, 0, k, hash_seed=k)
+    m.set_path("partitioned")
+    m.countFastq(text)
+    st = m.stats()
+    assert st["distinct"] == len(exp) and st["kmers_added"] == int(want.sum()) and st["insert_failures"] == 0
+    if len(exp):
+        assert np.array_equal(m.getKmerCounts(kmers), want)
+        x = kmers[0]
+        assert np.array_equal(m.hash_invert(m.hash_apply(x)), x)
+    m.close()
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

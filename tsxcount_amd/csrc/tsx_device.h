@@ -34,6 +34,19 @@ enum StatIdx {
     ST_N = 9
 };
 
+// Keys that cannot take the fast route of the partitioned path (a full log region, a hot k-mer merged on
+// chip, a full sub-list whose overflow queue is full too) wait here with their counts until the segment
+// build has finished; deferred_insert_kernel then inserts them like the atomic path would.  Nothing in the
+// scan and partition kernels touches the table, which is what lets a freshly cleared table skip its
+// memset (the build writes every segment).  In a sharded run the list is the caller's hot (key, count)
+// list, exchanged between the GPUs.  An entry is `rw` words of key (1, 2 or 4) and a count.
+struct DeferList {
+    uint64_t *rec;
+    uint64_t *cnt;
+    unsigned long long *n;   // entries appended so far (may run past cap: the excess is counted as lost)
+    uint64_t cap;
+};
+
 struct TableParams {
     uint64_t *table;            // slots * W limbs
     uint64_t *sec_keys;         // secondary array: slot position + 1
@@ -57,7 +70,22 @@ struct TableParams {
     uint32_t shard;             // this GPU's slot range: home slots [shard << l, (shard + 1) << l)
     int g, groups;              // LUT granularity (4 or 8 bits) and group count
     uint32_t max_reprobes;
+    DeferList defer;            // see DeferList; set per launch by the host
 };
+
+// Out of line on purpose (rare path; keeps the callers' register budgets): pk points at the kernel's own
+// TableParams argument (the kernel-argument segment).
+template <int RW>
+__device__ __attribute__((noinline)) void defer_append(const TableParams *pk, const uint64_t *r, uint64_t d) {
+    const unsigned long long at = atomicAdd(pk->defer.n, 1ULL);
+    if (at < pk->defer.cap) {
+#pragma unroll
+        for (int t = 0; t < RW; ++t) pk->defer.rec[at * RW + t] = r[t];
+        pk->defer.cnt[at] = d;
+    } else {
+        atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
+    }
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
 // every outstanding global load, store and atomic of the wave (s_waitcnt vmcnt(0)),

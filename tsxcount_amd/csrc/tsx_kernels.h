@@ -309,22 +309,6 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
 }
 
-// Rare ways out of scan_log_kernel (log region full, hot cache full, end-of-kernel hot cache
-// drain): kept out of line and fed from the kernel-argument segment so that the table
-// parameters insert_key() needs do not occupy scalar registers inside the strip loop.
-__device__ __attribute__((noinline)) void scan_side_insert(const TableParams *pk, uint64_t hkey, uint64_t d,
-                                                           uint64_t *hot_keys, uint64_t *hot_cnts, uint64_t hot_cap,
-                                                           unsigned long long *hot_n) {
-    if (hot_keys) {  // sharded table: the key may belong to another GPU
-        const unsigned long long at = atomicAdd(hot_n, 1ULL);
-        if (at < hot_cap) { hot_keys[at] = hkey; hot_cnts[at] = d; }
-        else atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
-    } else {
-        const uint64_t h1[1] = {hkey};
-        insert_key<1>(*pk, h1, d);
-    }
-}
-
 // Pass 3 of the partitioned path (k <= 32): scan -> 2-bit encode -> hash -> key log.
 // Same tile front end as count_fastq_kernel; what differs is what happens to a k-mer:
 //   * every LANE walks a strip of 16 consecutive start positions.  For one-limb keys the
@@ -347,8 +331,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
                                                          uint64_t own_end, int head_open, const uint32_t *tile_line,
                                                          uint64_t ntiles, int dbg, uint64_t *log, uint64_t log_cap,
                                                          unsigned long long *log_cnt, uint32_t *hist, uint32_t hist_nb,
-                                                         uint32_t hist_shift, uint64_t *hot_keys, uint64_t *hot_cnts,
-                                                         uint64_t hot_cap, unsigned long long *hot_n) {
+                                                         uint32_t hist_shift) {
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
     __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
     __shared__ uint64_t s_le[TILE / 64];
@@ -386,11 +369,13 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     // windows that may start at all: inside the text and inside this piece
     const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
 
-    // TableParams is the first kernel argument: the slow path reads it from the argument segment
+    // Rare ways out (log region full, hot cache full, end-of-kernel hot cache drain): the key joins the
+    // deferred list (tsx_device.h), out of line and fed from the kernel-argument segment (TableParams is the
+    // first kernel argument) so that nothing of it occupies registers inside the strip loop.
     const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     auto side_insert = [&](uint64_t hkey, uint64_t d) {
         if (dbg & 1) return;
-        scan_side_insert(pk, hkey, d, hot_keys, hot_cnts, hot_cap, hot_n);
+        defer_append<1>(pk, &hkey, d);
     };
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -574,7 +559,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
                                 my_log[at] = key;
                                 atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
                             } else {
-                                side_insert(key, 1);  // region full: atomic path (or the exchanged list)
+                                side_insert(key, 1);  // region full: deferred list (or the exchanged hot list)
                             }
                         }
                         fill += (uint32_t)__builtin_popcountll(mk);
@@ -585,6 +570,234 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     }
     lds_barrier();
     if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if (lane == 0) {
+        if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        log_cnt[region] = min(fill, cap32);
+    }
+    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
+}
+
+// Records of the partitioned path are RW 64-bit words: the WK limbs of the hashed key, padded to a power of
+// two so that 128-byte bursts hold whole records (k = 65..96: three limbs travel as four words).
+template <int WK> struct RecWords { static constexpr int value = (WK == 3) ? 4 : WK; };
+
+// r |= r >> s over three 64-bit words (1 <= s <= 64): the smear step of "a newline anywhere in [p, p+k)".
+__device__ __forceinline__ void shr_or3(uint64_t (&r)[3], uint32_t s) {
+    if (s >= 64) { r[0] |= r[1]; r[1] |= r[2]; return; }
+    r[0] |= (r[0] >> s) | (r[1] << (64u - s));
+    r[1] |= (r[1] >> s) | (r[2] << (64u - s));
+    r[2] |= r[2] >> s;
+}
+
+// Pass 3 of the partitioned path for multi-limb keys (k > 32; WK = 2..4).  Same tile front end and the same
+// strip idea as scan_log_kernel -- a lane walks 16 consecutive start positions, hashes the first window with
+// the LUT and every further one with the sliding update of x -> c*x in GF(2^2k),
+//     h' = (h >> 2) ^ roll[(h & 3) | out_base << 2 | in_base << 4]      (WK limbs per table entry),
+// and appends the hashes to its wave's log region with one ballot per position.  What differs:
+//   * the newline mask of a strip spans 16 + k - 1 <= 142 bytes: three words, smeared by doubling;
+//   * homopolymer k-mers (the A-tails) are recognised on the HASH: the mapping is a bijection, so
+//     h == hash(b repeated k times) says exactly that all k bases equal b.  They are counted per lane,
+//     summed over the wave and folded into the wave's hot cache; everything else is logged;
+//   * one position at a time (eight WK-limb hashes per lane would not fit the register budget).
+template <int WK>
+__global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, const uint8_t *buf, uint64_t n,
+                                                              uint64_t own_end, int head_open,
+                                                              const uint32_t *tile_line, uint64_t ntiles, int dbg,
+                                                              uint64_t *log, uint64_t log_cap,
+                                                              unsigned long long *log_cnt, uint32_t *hist,
+                                                              uint32_t hist_nb, uint32_t hist_shift) {
+    constexpr int RW = RecWords<WK>::value;
+    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
+    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
+    __shared__ uint64_t s_le[TILE / 64];
+    __shared__ uint8_t s_lb[TILE / 16];
+    __shared__ uint32_t s_wsum[NT / 64];
+    constexpr int HOT_N = 8;
+    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N * WK];
+    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hist[(NT / 64) * 512];
+    __shared__ uint64_t s_roll[64 * WK];
+    __shared__ uint64_t s_homh[4 * WK];
+    extern __shared__ uint64_t s_lut[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lut_words = p.groups * (1 << p.g) * WK;
+    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
+    for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
+    for (int i = tid; i < 64 * WK; i += NT) s_roll[i] = p.roll[i];
+    if (tid < 4) {   // straight from the global LUT: s_lut is not complete before the first barrier
+        uint64_t x[WK], hh[WK];
+#pragma unroll
+        for (int t = 0; t < WK; ++t) x[t] = 0x5555555555555555ULL * (uint64_t)tid;
+        x[WK - 1] &= p.top_mask;
+        hash_apply<WK>(p, p.lut, x, hh);
+#pragma unroll
+        for (int t = 0; t < WK; ++t) s_homh[tid * WK + t] = hh[t];
+    }
+    if (tid < (NT / 64) * HOT_N) s_hot_cnt[tid] = 0;
+    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
+    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
+    unsigned long long added = 0;
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
+    uint64_t *my_log = log + (uint64_t)region * log_cap * RW;
+    uint32_t *my_hist = s_hist + wave * 512;
+    uint32_t fill = 0;  // wave-uniform, in records
+    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
+    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint64_t lt = (1ULL << lane) - 1ULL;
+
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * TILE;
+        lds_barrier();  // previous tile's LDS fully consumed
+        {
+            const uint64_t off = base + (uint64_t)tid * 16;
+            uint32_t nl, le, code;
+            classify16(load16(buf, off, n), prev_is_nl(buf, off, n, head_open), nl, le, code);
+            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
+            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
+            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
+            if (tid < HALO / 16) {
+                const uint64_t hoff = base + TILE + (uint64_t)tid * 16;
+                uint32_t hnl, hle, hcode;
+                classify16(load16(buf, hoff, n), false, hnl, hle, hcode);
+                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
+                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
+            }
+            const uint32_t c = __popc(le);
+            const uint32_t inc = wave_incl_scan(c);
+            if (lane == 63) s_wsum[wave] = inc;
+            lds_barrier();
+            uint32_t woff = tile_line[tile];
+            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        lds_barrier();
+
+        const uint32_t s0 = (uint32_t)tid * 16;
+        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
+        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
+        // newline flags of bytes [s0, s0 + 160): a window of position j <= 15 reaches byte s0 + 15 + k - 1 <= s0 + 141
+        uint64_t r[3];
+        {
+            const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
+            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2], a3 = nl32[w + 3], a4 = nl32[w + 4],
+                           a5 = nl32[w + 5];
+            r[0] = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
+            r[1] = (uint64_t)__funnelshift_r(a2, a3, sh) | ((uint64_t)__funnelshift_r(a3, a4, sh) << 32);
+            r[2] = (uint64_t)__funnelshift_r(a4, a5, sh);
+        }
+        {   // bad_j = a newline in [s0+j, s0+j+k): OR of the mask shifted by 0..k-1, by doubling
+            uint32_t span = 1;
+            while (span * 2 <= k) { shr_or3(r, span); span *= 2; }
+            if (span < k) shr_or3(r, k - span);
+        }
+        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
+        const uint32_t lb = s_lb[tid];
+        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
+        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
+        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
+        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
+        const uint64_t g0 = base + s0;
+        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
+        const uint32_t vm = ~(uint32_t)r[0] & b0 & ~b1 & ((1u << jmax) - 1u);   // line & 3 == 1, no newline, in range
+        added += (unsigned long long)__popc(vm);
+        if (__ballot(vm != 0u) == 0ULL) continue;   // header, '+' and quality lines: nothing starts here
+
+        uint64_t h[WK];
+#pragma unroll
+        for (int t = 0; t < WK; ++t) h[t] = 0;
+        if (vm) {
+            uint64_t x[WK];
+            extract_kmer<WK>(s_codes, s0, p.top_mask, x);
+            hash_apply<WK>(p, (const uint64_t *)s_lut, x, h);
+        }
+        // bases leaving (s0+j) and entering (s0+j+k) when the window moves from j to j+1
+        const uint32_t cw0 = codes32[tid];
+        uint32_t inc;
+        {
+            const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
+            inc = __funnelshift_r(codes32[tid + ws], codes32[tid + ws + 1], sh);
+        }
+        uint32_t homcnt = 0;   // four 8-bit counters: homopolymer k-mers of base b seen in this strip
+        for (uint32_t j = 0; j < 16; ++j) {
+            const bool valid = (vm >> j) & 1u;
+            const uint32_t ob = __builtin_amdgcn_ubfe(cw0, 2u * j, 2u);
+            bool hom = valid && h[0] == s_homh[ob * WK];
+            if (hom) {
+#pragma unroll
+                for (int t = 1; t < WK; ++t) hom &= (h[t] == s_homh[ob * WK + t]);
+            }
+            homcnt += hom ? (1u << (8u * ob)) : 0u;
+            const bool em = valid && !hom;
+            const unsigned long long mk = __ballot(em);
+            if (mk) {
+                if (em) {
+                    const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & lt);
+                    if (at < cap32) {
+                        uint64_t *o = my_log + (uint64_t)at * RW;
+#pragma unroll
+                        for (int t = 0; t < RW; ++t) o[t] = (t < WK) ? h[t < WK ? t : 0] : 0ULL;
+                        atomicAdd(&my_hist[(uint32_t)(h[0] >> hist_shift) & (hist_nb - 1)], 1u);
+                    } else if (!(dbg & 1)) {
+                        uint64_t rec[RW];
+#pragma unroll
+                        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? h[t < WK ? t : 0] : 0ULL;
+                        defer_append<RW>(pk, rec, 1);   // region full
+                    }
+                }
+                fill += (uint32_t)__builtin_popcountll(mk);
+            }
+            if (j < 15) {
+                const uint32_t idx = ((uint32_t)h[0] & 3u) | (ob << 2) | (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
+#pragma unroll
+                for (int t = 0; t < WK; ++t) {
+                    uint64_t v = h[t] >> 2;
+                    if (t + 1 < WK) v |= h[t + 1] << 62;
+                    h[t] = v ^ s_roll[idx * WK + t];
+                }
+            }
+        }
+        if (__ballot(homcnt != 0u)) {
+            for (uint32_t b = 0; b < 4; ++b) {
+                uint32_t tot = (homcnt >> (8u * b)) & 0xFFu;
+                if (__ballot(tot != 0u) == 0ULL) continue;
+                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                if (lane == 0) {
+                    uint64_t *hkey = s_hot_key + (size_t)wave * HOT_N * WK;
+                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                    int at = -1;
+                    for (int q = 0; q < HOT_N && at < 0; ++q) {
+                        if (!hcnt[q]) continue;
+                        bool same = true;
+                        for (int t = 0; t < WK; ++t) same &= (hkey[q * WK + t] == s_homh[b * WK + t]);
+                        if (same) at = q;
+                    }
+                    if (at < 0)
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (!hcnt[q]) {
+                                at = q;
+                                for (int t = 0; t < WK; ++t) hkey[q * WK + t] = s_homh[b * WK + t];
+                                break;
+                            }
+                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                    else if (!(dbg & 1)) {
+                        uint64_t rec[RW];
+                        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? s_homh[b * WK + (t < WK ? t : 0)] : 0ULL;
+                        defer_append<RW>(pk, rec, tot);
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid] && !(dbg & 1)) {
+        uint64_t rec[RW];
+        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? s_hot_key[(size_t)tid * WK + (t < WK ? t : 0)] : 0ULL;
+        defer_append<RW>(pk, rec, s_hot_cnt[tid]);
+    }
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
     if (lane == 0) {
         if (added) atomicAdd(&p.stats[ST_KMERS], added);

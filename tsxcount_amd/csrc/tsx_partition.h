@@ -1,84 +1,90 @@
-// tsx_partition.h -- the partitioned insert path (k <= 32, one-limb slots).
+// tsx_partition.h -- the partitioned insert path.
 //
 // Random 64-bit global atomics top out at ~17 G/s on MI355X whatever the
 // footprint (profiles/round1_atomics_ubench.txt), so for large inputs the table
 // is not updated in place.  Instead:
-//   scan_log_kernel        (tsx_kernels.h) writes hashed keys to one log region per
-//                          wave and keeps a level-1 histogram per region (no atomics)
+//   scan_log_kernel / scan_log_wide_kernel  (tsx_kernels.h) write hashed keys to one log
+//                          region per wave and keep a level-1 histogram per region (no atomics)
 //   offsets_*_kernel       exclusive scan of the histograms -> exact write offsets
-//   partition_ring_kernel  x1 or x2: radix-scatters keys by the high bits of their
+//   partition_ring_kernel  x1 or x2: radix-scatters records by the high bits of their
 //                          home slot into one list per table segment, through LDS
 //                          ring staging and 128-B bursts
 //   build_segments_kernel  one workgroup per 2^S-slot segment: segment in LDS,
 //                          inserts with LDS atomics, streamed back once
+//                          (build_segments_wide_kernel: multi-limb keys and slots)
+//   overflow_insert_kernel, deferred_insert_kernel: what did not fit a list, inserted
+//                          like the atomic path would -- AFTER the build
 //   split_owner_kernel, hist_kernel, add_hashed_kernel: the sharded (multi-GPU) legs
-// All HBM traffic is sequential.  Anything that does not fit a list (skewed
-// data) falls back to insert_key(), i.e. the atomic path: slower, same result.
+// All HBM traffic is sequential.  A record is RW 64-bit words (RecWords<WK>): the WK limbs of
+// the hashed key, padded to 1, 2 or 4 words.  Scan and partition never touch the table:
+// whatever cannot take the fast route waits in queues (DeferList, tsx_device.h) until the
+// build has written its segments, so a freshly cleared table needs no memset.
 #pragma once
 #include "tsx_kernels.h"
 
 namespace tsx {
 
 constexpr int PART_NT = 256;
-constexpr int PART_RPT = 8;      // keys per thread per batch
-constexpr int PART_FLUSH = 16;   // keys per burst (128 B = one L2 line)
+constexpr int PART_WPT = 8;      // words per thread per batch (8 / RW records)
+constexpr int PART_FLUSH = 16;   // words per burst (128 B = one L2 line)
+
+template <int RW>
+__device__ __forceinline__ void load_rec(const uint64_t *ptr, uint64_t (&r)[RW]) {
+    if constexpr (RW == 1) {
+        r[0] = *ptr;
+    } else {
+#pragma unroll
+        for (int t = 0; t < RW; t += 2) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(ptr + t);
+            r[t] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+            r[t + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        }
+    }
+}
+template <int RW>
+__device__ __forceinline__ void store_rec(uint64_t *ptr, const uint64_t (&r)[RW]) {
+    if constexpr (RW == 1) {
+        *ptr = r[0];
+    } else {
+#pragma unroll
+        for (int t = 0; t < RW; t += 2)
+            *reinterpret_cast<uint4 *>(ptr + t) = make_uint4((uint32_t)r[t], (uint32_t)(r[t] >> 32), (uint32_t)r[t + 1],
+                                                             (uint32_t)(r[t + 1] >> 32));
+    }
+}
 
 // Atomic-free radix level.  A workgroup (r, c) takes every cpr-th batch of source
 // region r and owns the write cursors of its destination lists, which therefore
 // live in LDS (returning atomics on shared cursors cost 12 of 17 ms in the first
 // version).  Two uses:
-//   level 1  region = one scan workgroup's key log, cpr = 1; cursor[b] starts at the
+//   level 1  region = one scan wave's key log, cpr = 1; cursor[b] starts at the
 //            exact offset offs[b * nregions + r] that offsets_kernel derived from the
 //            scan kernel's histograms: the output is a packed array ordered by bucket
-//   level 2  region = one level-1 bucket (start/count from offsets_kernel); the keys
+//   level 2  region = one level-1 bucket (start/count from offsets_kernel); the records
 //            of segment (r * nb + b) go to sub-list ((r * nb + b) * cpr + c) with
-//            room for dst_cap keys; its final size is published to dst_cnt
-// Staging is a ring of 2^capbits keys per list (no compaction after a flush).
-// A flush is (A) one thread per list: how many keys (multiple of PART_FLUSH = one
+//            room for dst_cap records; its final size is published to dst_cnt
+// Sizes and offsets at the interface count RECORDS; inside, rings, cursors and bursts count
+// 64-bit WORDS (a record is RW of them, RW | 16), so the staging logic is the same for every
+// key width.  Staging is a ring of 2^capbits words per list (no compaction after a flush).
+// A flush is (A) one thread per list: how many words (multiple of PART_FLUSH = one
 // 128-B line; 64-B bursts cost 0.8 ms more in level 1) and where; (B) 8 consecutive
 // lanes per list copy them, with the LDS reads of all lists an octet serves issued
 // before the first store.
 // What does not fit a destination list (level 2 sub-lists under skew): almost always a handful of hot
 // keys (k-mers that occur once per read, thousands of times in all).  They are folded into a small LDS
-// cache and reach the table through ONE atomic insert per key and workgroup at the end, instead of one
-// contended atomic per occurrence.  Out of line, fed from the kernel-argument segment: the slow path and
-// insert_key() would otherwise be inlined at every store of the flush and serialise the scatter.
+// cache and join the deferred list with their totals when the workgroup ends, instead of one queue entry
+// per occurrence; ordinary records displaced by them go to the workgroup's overflow queue.
 constexpr uint32_t OVF_N = 64;
 constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
-__device__ __attribute__((noinline)) void part_spill(const TableParams *pk, uint64_t key, uint64_t *ovk, uint32_t *ovc,
-                                                     uint64_t *ovq, uint32_t *ovn, uint32_t ovq_cap) {
-    const uint64_t kk = key ^ OVF_SALT;
-    if (kk != 0) {
-        uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
-        for (int pr = 0; pr < 4; ++pr) {
-            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&ovk[slot]), 0ULL,
-                                                     (unsigned long long)kk);
-            if (old == 0ULL || old == kk) { atomicAdd(&ovc[slot], 1u); return; }
-            slot = (slot + 1) & (OVF_N - 1);
-        }
-    }
-    // Not a cached hot key: an ordinary key that found its list filled up by one.  It goes to this
-    // workgroup's overflow queue (plain store; overflow_insert_kernel inserts the queues afterwards, all
-    // lanes of the chip at once).  Inserting right here cost 1.7 ms: a dependent global CAS per key, one
-    // workgroup after all others had finished.
-    if (ovq) {
-        const uint32_t at = atomicAdd(ovn, 1u);
-        if (at < ovq_cap) { ovq[at] = key; return; }
-    }
-    const uint64_t h[1] = {key};
-    insert_key<1>(*pk, h, 1);
-}
-__device__ __attribute__((noinline)) void part_insert(const TableParams *pk, uint64_t key, uint64_t d) {
-    const uint64_t h[1] = {key};
-    insert_key<1>(*pk, h, d);
-}
 
 constexpr int PART_ITER = 4;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
+template <int RW>
 __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap) {
+    constexpr int RPT = PART_WPT / RW;                 // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
@@ -89,51 +95,80 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     uint32_t *s_head = s_tail + nb;
     uint32_t *s_job = s_head + nb;      // lists with something to flush this round, in arrival order
     __shared__ uint32_t s_njobs[2];     // their number; two counters used alternately (reset one round ahead)
-    __shared__ uint32_t s_ovn;          // keys in this workgroup's overflow queue
-    __shared__ uint64_t s_ovk[OVF_N];   // spilled hot keys (xor OVF_SALT, 0 = free) and their counts
+    __shared__ uint32_t s_ovn;          // records in this workgroup's overflow queue
+    __shared__ uint64_t s_ovk[OVF_N * RW];   // spilled hot keys (word 0 xor OVF_SALT, 0 = free) and their counts
     __shared__ uint32_t s_ovc[OVF_N];
+    __shared__ uint32_t s_ovr[OVF_N];   // RW > 1: the other words of the cached key have been written
     const uint32_t tid = threadIdx.x;
     const uint32_t r = blockIdx.x / cpr, c = blockIdx.x % cpr;
     if (r >= nregions) return;
-    if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
+    if (tid < OVF_N) { s_ovk[tid * RW] = 0; s_ovc[tid] = 0; s_ovr[tid] = 0; }
     if (tid < 2) s_njobs[tid] = 0;
     if (tid == 0) s_ovn = 0;
-    uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
+    uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap * RW : nullptr;
     for (uint32_t b = tid; b < nb; b += PART_NT) {
         s_tail[b] = 0; s_head[b] = 0;
-        if (offs) { s_cur[b] = offs_base[b] + offs[(size_t)b * nregions + r]; s_lim[b] = ~0ULL; }
-        else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap; s_lim[b] = s_cur[b] + dst_cap; }
+        if (offs) { s_cur[b] = (offs_base[b] + offs[(size_t)b * nregions + r]) * RW; s_lim[b] = ~0ULL; }
+        else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap * RW; s_lim[b] = s_cur[b] + dst_cap * RW; }
     }
     lds_barrier();
-    const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);
-    const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
-    constexpr uint64_t BATCH_REC = (uint64_t)PART_NT * PART_RPT;
+    const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);   // records
+    const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap) * RW;
+    constexpr uint64_t BATCH_REC = (uint64_t)PART_NT * RPT;
     const uint64_t stride = (uint64_t)cpr * BATCH_REC;
 
     // TableParams is the first kernel argument: the slow paths read it from the argument segment
     const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     uint32_t spilled = 0;  // per thread; one atomic per wave at the end
-    // In line: one probe of the spill cache (a cached hot key hits it) and the overflow queue (an
-    // ordinary key misses).  A call here makes the wave wait for every store it has in flight.
-    auto spill = [&](uint64_t key) {
+    // A record that found its list full.  In line: one probe of the spill cache (a cached hot key hits it)
+    // and the overflow queue (an ordinary record misses); the deferred list takes what the queue cannot.
+    auto spill = [&](const uint64_t (&rec)[RW]) {
         ++spilled;
-        const uint64_t kk = key ^ OVF_SALT;
+        const uint64_t kk = rec[0] ^ OVF_SALT;
         if (kk != 0) {
-            const uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
-            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot]), 0ULL,
+            uint64_t mixin = rec[0];
+#pragma unroll
+            for (int t = 1; t < RW; ++t) mixin ^= rec[t];
+            const uint32_t slot = (uint32_t)(mix64(mixin) >> 40) & (OVF_N - 1);
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot * RW]), 0ULL,
                                                      (unsigned long long)kk);
-            if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
+            if constexpr (RW == 1) {
+                if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
+            } else {
+                if (old == 0ULL) {   // claimed: publish the other words, then the ready flag
+#pragma unroll
+                    for (int t = 1; t < RW; ++t) s_ovk[slot * RW + t] = rec[t];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(&s_ovr[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicAdd(&s_ovc[slot], 1u);
+                    return;
+                }
+                if (old == kk && __hip_atomic_load(&s_ovr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    bool same = true;
+#pragma unroll
+                    for (int t = 1; t < RW; ++t) same &= (s_ovk[slot * RW + t] == rec[t]);
+                    if (same) { atomicAdd(&s_ovc[slot], 1u); return; }
+                }
+            }
         }
         if (ovq) {
             const uint32_t at = atomicAdd(&s_ovn, 1u);
-            if (at < ovq_cap) { ovq[at] = key; return; }
+            if (at < ovq_cap) { store_rec<RW>(ovq + (size_t)at * RW, rec); return; }
         }
-        part_spill(pk, key, s_ovk, s_ovc, ovq, &s_ovn, ovq_cap);
+        defer_append<RW>(pk, rec, 1);
     };
-    auto put = [&](uint64_t key, unsigned long long at, unsigned long long lim) {
+    // one word of a burst: word q of the burst that starts at ring index hd of `ring` and at destination `at`
+    auto put_word = [&](uint64_t w, const uint64_t *ring, uint32_t hd, uint32_t q, unsigned long long at,
+                        unsigned long long lim) {
         if (dbg & 256) return;  // ablation: no stores
-        if (at < lim) dst[at] = key;
-        else spill(key);  // sub-list full
+        if (at + q < lim) { dst[at + q] = w; return; }
+        if ((q & (RW - 1)) == 0) {   // sub-list full: the lane that holds the record's first word spills all of it
+            uint64_t rec[RW];
+#pragma unroll
+            for (int t = 0; t < RW; ++t) rec[t] = ring[(hd + q + t) & cmask];
+            spill(rec);
+        }
     };
     uint32_t round = 0;   // flush rounds so far (workgroup-uniform)
     auto flush = [&](bool all) {
@@ -183,54 +218,62 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             }
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t nout = (uint32_t)(meta[u] & 0xFF);
+                const uint32_t nout = (uint32_t)(meta[u] & 0xFF), hd = (uint32_t)(meta[u] >> 8) & 0xFF;
                 const unsigned long long at = meta[u] >> 16;
-                if (ol < nout) put(k0[u], at + ol, lim[u]);
-                if (ol + 8 < nout) put(k1[u], at + ol + 8, lim[u]);
-                if (nout > 16) {  // only rings deeper than 16 or the final flush get here
-                    const uint32_t hd = (uint32_t)(meta[u] >> 8) & 0xFF;
-                    const uint64_t *ring = s_stage + ((size_t)bj[u] << capbits);
-                    for (uint32_t q = ol + 16; q < nout; q += 8) put(ring[(hd + q) & cmask], at + q, lim[u]);
-                }
+                const uint64_t *ring = s_stage + ((size_t)bj[u] << capbits);
+                if (ol < nout) put_word(k0[u], ring, hd, ol, at, lim[u]);
+                if (ol + 8 < nout) put_word(k1[u], ring, hd, ol + 8, at, lim[u]);
+                if (nout > 16)   // only rings deeper than 16 or the final flush get here
+                    for (uint32_t q = ol + 16; q < nout; q += 8) put_word(ring[(hd + q) & cmask], ring, hd, q, at, lim[u]);
             }
         }
     };
 
-    uint64_t cur[PART_RPT], nxt[PART_RPT];
+    uint64_t cur[RPT][RW], nxt[RPT][RW];
     uint64_t base = (uint64_t)c * BATCH_REC;
 #pragma unroll
-    for (int q = 0; q < PART_RPT; ++q) {
+    for (int q = 0; q < RPT; ++q) {
         const uint64_t i = base + (uint64_t)q * PART_NT + tid;
-        cur[q] = (i < n) ? in[i] : 0;
+        if (i < n) load_rec<RW>(in + i * RW, cur[q]);
+        else {
+#pragma unroll
+            for (int t = 0; t < RW; ++t) cur[q][t] = 0;
+        }
     }
     for (; base < n; base += stride) {
 #pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             const uint64_t i = base + stride + (uint64_t)q * PART_NT + tid;
-            nxt[q] = (i < n) ? in[i] : 0;
+            if (i < n) load_rec<RW>(in + i * RW, nxt[q]);
+            else {
+#pragma unroll
+                for (int t = 0; t < RW; ++t) nxt[q][t] = 0;
+            }
         }
-        // all ring places of the batch are taken before any is used: the eight returning LDS atomics
+        // all ring places of the batch are taken before any is used: the returning LDS atomics
         // of a thread are in flight together
-        uint32_t bq[PART_RPT], slot[PART_RPT], head[PART_RPT];
+        uint32_t bq[RPT], slot[RPT], head[RPT];
 #pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             const uint64_t i = base + (uint64_t)q * PART_NT + tid;
-            bq[q] = (uint32_t)(cur[q] >> shift) & (nb - 1);
-            slot[q] = (i < n) ? atomicAdd(&s_tail[bq[q]], 1u) : 0u;
+            bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
+            slot[q] = (i < n) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) head[q] = s_head[bq[q]];
+        for (int q = 0; q < RPT; ++q) head[q] = s_head[bq[q]];
 #pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) {
+        for (int q = 0; q < RPT; ++q) {
             const uint64_t i = base + (uint64_t)q * PART_NT + tid;
             if (i < n) {
-                const uint64_t key = cur[q];
                 const uint32_t b = bq[q];
-                if (slot[q] - head[q] < CAP) {
-                    s_stage[((size_t)b << capbits) + (slot[q] & cmask)] = key;
-                } else {  // ring full: take the next place of the list directly
-                    const unsigned long long at = atomicAdd(&s_cur[b], 1ULL);
-                    put(key, at, s_lim[b]);
+                if (slot[q] - head[q] < CAP) {   // RW | CAP and records are RW-aligned: a record never wraps
+                    uint64_t *ring = s_stage + ((size_t)b << capbits) + (slot[q] & cmask);
+#pragma unroll
+                    for (int t = 0; t < RW; ++t) ring[t] = cur[q][t];
+                } else if (!(dbg & 256)) {  // ring full: take the next place of the list directly
+                    const unsigned long long at = atomicAdd(&s_cur[b], (unsigned long long)RW);
+                    if (at < s_lim[b]) store_rec<RW>(dst + at, cur[q]);
+                    else spill(cur[q]);
                 }
             }
         }
@@ -238,30 +281,62 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         flush(false);
         lds_barrier();
 #pragma unroll
-        for (int q = 0; q < PART_RPT; ++q) cur[q] = nxt[q];
+        for (int q = 0; q < RPT; ++q)
+#pragma unroll
+            for (int t = 0; t < RW; ++t) cur[q][t] = nxt[q][t];
     }
     flush(true);
     lds_barrier();
     if (dst_cnt)
         for (uint32_t b = tid; b < nb; b += PART_NT) {
             const uint64_t li = ((uint64_t)r * nb + b) * cpr + c;
-            dst_cnt[li] = min(s_cur[b], s_lim[b]) - li * dst_cap;
+            dst_cnt[li] = (min(s_cur[b], s_lim[b]) - li * dst_cap * RW) / RW;
         }
-    if (tid < OVF_N && s_ovc[tid]) part_insert(pk, s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
+    if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) {   // hot keys: one deferred entry each, with the total
+        uint64_t rec[RW];
+#pragma unroll
+        for (int t = 0; t < RW; ++t) rec[t] = s_ovk[tid * RW + t];
+        rec[0] ^= OVF_SALT;
+        defer_append<RW>(pk, rec, s_ovc[tid]);
+    }
     if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
     for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
     if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
 }
 
-// Inserts the overflow queues partition_ring_kernel left behind (one queue of `cap` places per workgroup).
+// Inserts the overflow queues partition_ring_kernel left behind (one queue of `cap` records per
+// workgroup) -- after the segment build, like every insert that goes to the table directly.
+template <int WK>
 __global__ __launch_bounds__(PART_NT) void overflow_insert_kernel(TableParams p, const uint64_t *ovq_all,
                                                                   const uint32_t *ovq_cnt, uint32_t cap, uint32_t nq) {
+    constexpr int RW = RecWords<WK>::value;
     for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
         const uint32_t n = ovq_cnt[qi];
         for (uint32_t i = threadIdx.x; i < n; i += PART_NT) {
-            const uint64_t h[1] = {ovq_all[(size_t)qi * cap + i]};
-            insert_key<1>(p, h, 1);
+            uint64_t h[WK];
+#pragma unroll
+            for (int t = 0; t < WK; ++t) h[t] = ovq_all[((size_t)qi * cap + i) * RW + t];
+            insert_key<WK>(p, h, 1);
         }
+    }
+}
+
+// Inserts the deferred list (DeferList, tsx_device.h): hot k-mers with their totals, records of full log
+// regions, records that found sub-list and overflow queue full.  Keys of other shards are skipped (the
+// exchanged hot lists of a sharded run reach every GPU).
+template <int WK>
+__global__ __launch_bounds__(PART_NT) void deferred_insert_kernel(TableParams p, const uint64_t *rec, const uint64_t *cnt,
+                                                                  const unsigned long long *n_ptr, uint64_t n_fixed,
+                                                                  uint64_t cap) {
+    constexpr int RW = RecWords<WK>::value;
+    const uint64_t n = min(n_ptr ? (uint64_t)*n_ptr : n_fixed, cap);
+    for (uint64_t i = (uint64_t)blockIdx.x * PART_NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PART_NT) {
+        uint64_t h[WK];
+#pragma unroll
+        for (int t = 0; t < WK; ++t) h[t] = rec[i * RW + t];
+        const uint64_t d = cnt ? cnt[i] : 1ULL;
+        if (d == 0 || (p.lg != p.l && owner_shard<WK>(p, h) != p.shard)) continue;
+        insert_key<WK>(p, h, d);
     }
 }
 
@@ -405,8 +480,8 @@ __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uin
     }
 }
 
-// addKmer for HASHED keys with counts (the exchanged hot-key lists of a sharded run);
-// keys of other shards are skipped.
+// addKmer for HASHED keys (tiny sharded tables that cannot be partitioned); keys of other shards
+// are skipped.  key_sum: see hist_kernel.
 __global__ __launch_bounds__(PART_NT) void add_hashed_kernel(TableParams p, const uint64_t *keys, const uint64_t *counts,
                                                              uint64_t n, unsigned long long *key_sum) {
     unsigned long long sum = 0;
@@ -427,12 +502,14 @@ __global__ __launch_bounds__(PART_NT) void add_hashed_kernel(TableParams p, cons
 // while the segment's key list is inserted with LDS atomics (same slot format,
 // same probe sequence as insert_key), then go back to HBM in one sweep.
 // Segments that already hold data (seg_dirty) are loaded first; untouched
-// segments with an empty list are skipped.
+// segments with an empty list are skipped -- unless the table is `fresh` (cleared but not
+// zeroed, tsx_hip_clear): then nothing is loaded and a segment without keys is written as zeros,
+// so that after the build every slot of the table has been written exactly once.
 __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, const uint64_t *lists,
                                                               const unsigned long long *list_start,
                                                               const unsigned long long *list_cnt,
                                                               uint64_t list_cap, uint32_t pieces, uint32_t nseg,
-                                                              int dbg) {
+                                                              int dbg, int fresh) {
     extern __shared__ uint64_t s_seg[];  // 2^S slots
     __shared__ uint32_t s_pn[8];         // sizes of the segment's sub-lists
     const uint32_t nslots = 1u << p.S;
@@ -446,17 +523,24 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
             n = (uint64_t)list_cnt[seg];
             in0 = lists + (uint64_t)list_start[seg];
             npieces = 1;
-            if (tid == 0) s_pn[0] = (uint32_t)n;
         } else {
             for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
             in0 = lists + (uint64_t)seg * pieces * list_cap;
             npieces = pieces;
-            if (tid < pieces) s_pn[tid] = (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + tid], list_cap);
         }
-        if (n == 0) continue;
         uint64_t *slots = p.table + ((uint64_t)seg << p.S);
-        const bool dirty = p.seg_dirty[seg] != 0;
+        if (n == 0) {
+            if (fresh) {   // nothing to insert, but the stale slots must go
+                for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
+                    *reinterpret_cast<uint4 *>(&slots[i]) = make_uint4(0, 0, 0, 0);
+                if (tid == 0) p.seg_dirty[seg] = 0;
+            }
+            continue;
+        }
+        const bool dirty = !fresh && p.seg_dirty[seg] != 0;
         lds_barrier();  // previous segment fully written out
+        if (list_start) { if (tid == 0) s_pn[0] = (uint32_t)n; }
+        else if (tid < pieces) s_pn[tid] = (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + tid], list_cap);
         if (dirty) {
             for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
                 *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
@@ -534,6 +618,144 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
         lds_barrier();
         if (!(dbg & 4))
             for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);
+        if (tid == 0) p.seg_dirty[seg] = 1;
+    }
+}
+
+// The same for multi-limb keys and/or multi-limb slots (k > 32, or wide counters): records of RW words,
+// slots of W words in LDS (AoS, like the table).  Limb 0 is claimed by a 64-bit LDS CAS with the LOCK bit
+// set, the claimant writes limbs 1..W-1 and then stores limb 0 without LOCK -- the protocol of insert_key
+// with LDS operations; a lane whose limb-0 key bits match a locked slot looks again in the next round (the
+// claimant, possibly a lane of the same wave, has published by then: the loop has no early exit).
+template <int WK>
+__global__ __launch_bounds__(1024) void build_segments_wide_kernel(TableParams p, const uint64_t *lists,
+                                                                   const unsigned long long *list_start,
+                                                                   const unsigned long long *list_cnt,
+                                                                   uint64_t list_cap, uint32_t pieces, uint32_t nseg,
+                                                                   int dbg, int fresh) {
+    constexpr int RW = RecWords<WK>::value;
+    extern __shared__ uint64_t s_seg[];  // 2^S slots of W words
+    __shared__ uint32_t s_pn[8];
+    const uint32_t W = (uint32_t)p.W;
+    const uint32_t nwords = (1u << p.S) * W;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        uint64_t n = 0;
+        const uint64_t *in0;
+        uint32_t npieces;
+        if (list_start) {
+            n = (uint64_t)list_cnt[seg];
+            in0 = lists + (uint64_t)list_start[seg] * RW;
+            npieces = 1;
+        } else {
+            for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
+            in0 = lists + (uint64_t)seg * pieces * list_cap * RW;
+            npieces = pieces;
+        }
+        uint64_t *slots = p.table + ((uint64_t)seg << p.S) * W;
+        if (n == 0) {
+            if (fresh) {
+                for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+                    *reinterpret_cast<uint4 *>(&slots[i]) = make_uint4(0, 0, 0, 0);
+                if (tid == 0) p.seg_dirty[seg] = 0;
+            }
+            continue;
+        }
+        const bool dirty = !fresh && p.seg_dirty[seg] != 0;
+        lds_barrier();
+        if (list_start) { if (tid == 0) s_pn[0] = (uint32_t)n; }
+        else if (tid < pieces) s_pn[tid] = (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + tid], list_cap);
+        if (dirty) {
+            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
+        } else {
+            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
+        }
+        lds_barrier();
+        const uint64_t one = 1ULL << p.cshift;
+        uint32_t grp = 0, gl = tid, gstride = nt;
+        if (npieces > 1) {
+            gstride = nt / npieces;
+            grp = tid / gstride;
+            gl = tid - grp * gstride;
+        }
+        const uint32_t mine = (grp < npieces) ? s_pn[grp] : 0u;
+        const uint64_t *ptr = in0 + ((uint64_t)grp * list_cap + gl) * RW;
+        uint32_t left = (gl < mine) ? (mine - gl + gstride - 1) / gstride : 0;
+        const uint32_t smask = (uint32_t)p.seg_mask;
+        const uint64_t k0mask = p.k0mask, lock = p.lock_bit;
+        const uint32_t maxr = p.max_reprobes;
+        bool live = (left > 0) && !(dbg & 2);
+        // the next record is in flight while the current one probes
+        uint64_t nxt[RW];
+        if (left > 0) load_rec<RW>(ptr, nxt);
+        else {
+#pragma unroll
+            for (int t = 0; t < RW; ++t) nxt[t] = 0;
+        }
+        uint64_t e0 = 0, hi[4] = {0, 0, 0, 0};
+        uint32_t i = 1, q = 0, spins = 0;
+        bool fresh_key = true;
+        while (live) {
+            if (fresh_key) {
+                uint64_t h[WK], pos0;
+#pragma unroll
+                for (int t = 0; t < WK; ++t) h[t] = nxt[t];
+                split_key<WK>(p, h, pos0, e0, hi);
+                i = 1;
+                q = ((uint32_t)pos0 + 1u) & smask;
+                ptr += (uint64_t)gstride * RW;
+                if (left > 1) load_rec<RW>(ptr, nxt);
+                fresh_key = false;
+            }
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(&s_seg[(size_t)q * W]);
+            const uint64_t key0 = e0 | i;
+            const unsigned long long old = atomicCAS(slot, 0ULL, (unsigned long long)(key0 | lock | one));
+            bool placed = false, next = false;
+            if (old == 0ULL) {
+                if (W > 1) {
+                    for (uint32_t t = 1; t < W; ++t) slot[t] = hi[t - 1];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(slot, (unsigned long long)(key0 | one), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                placed = true;
+            } else if ((old & k0mask) != key0) {
+                next = true;
+            } else if (W > 1 && (old & lock)) {
+                // claimed, limbs not published yet: probe the same slot again in the next round (bounded: a
+                // lock that never clears must not hang the chip -- it is reported through ST_LOCKTO)
+                if (++spins > (1u << 20)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); spins = 0; next = true; }
+            } else {
+                bool same = true;
+                if (W > 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    for (uint32_t t = 1; t < W; ++t) same &= (slot[t] == hi[t - 1]);
+                }
+                if (same) {
+                    const unsigned long long prev = atomicAdd(slot, (unsigned long long)one);
+                    const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
+                    if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
+                    placed = true;
+                } else {
+                    next = true;
+                }
+            }
+            if (next) {
+                if (i >= maxr) { atomicAdd(&p.stats[ST_FAIL], 1ULL); placed = true; }
+                ++i;
+                q = (q + i) & smask;
+            }
+            if (placed) {
+                live = --left > 0;
+                fresh_key = true;
+                spins = 0;
+            }
+        }
+        lds_barrier();
+        if (!(dbg & 4))
+            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
                 *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);
         if (tid == 0) p.seg_dirty[seg] = 1;
     }

@@ -49,10 +49,16 @@ struct tsx_hip_map {
     std::vector<uint64_t> rows, irows;   // n x wk
     std::vector<uint64_t> lut, ilut;     // [groups][1<<g][wk]
     uint64_t *d_lut = nullptr, *d_ilut = nullptr, *d_roll = nullptr;
-    uint64_t *d_ovq = nullptr;           // overflow queues of the level-2 partition (OVQ_CAP keys per workgroup)
+    uint64_t *d_ovq = nullptr;           // overflow queues of the level-2 partition (OVQ_CAP records per workgroup)
+    uint64_t *d_def_rec = nullptr, *d_def_cnt = nullptr;   // deferred list (DeferList, tsx_device.h)
+    unsigned long long *d_def_n = nullptr;
+    size_t def_cap = 0;
+    bool fresh = false;                  // tsx_hip_clear() was called and the table itself has not been zeroed yet:
+                                         // the next partitioned build writes every segment, anything else zeroes first
     uint32_t *d_ovq_cnt = nullptr;
     size_t ovq_queues = 0;
     uint64_t roll[64] = {0};             // one-limb keys: sliding-window hash update table
+    std::vector<uint64_t> roll_wide;     // multi-limb keys: the same, key_limbs words per entry
     // FASTQ scratch
     uint32_t *d_tile = nullptr; uint64_t tile_cap = 0;
     uint32_t *d_carry = nullptr;
@@ -86,6 +92,9 @@ struct tsx_hip_map {
 };
 
 static const size_t STAGE_PAD = 256;
+static bool can_partition(const tsx_hip_map *m);
+static int clear_impl(tsx_hip_map *m, bool full);
+static int ensure_zeroed(tsx_hip_map *m, hipStream_t st);
 
 extern "C" int tsx_hip_key_limbs(int k) { return (k < 1 || k > 127) ? TSX_HIP_EINVAL : (2 * k + 63) / 64; }
 
@@ -172,20 +181,66 @@ static inline uint64_t gf_mul(uint64_t a, uint64_t b, uint64_t plow, int n) {
     return r;
 }
 
+// Degrees 66..254 (multi-limb keys): x^n + x^a [+ x^b + x^c] + 1, found by scripts/find_irreducible.py
+// (Rabin's test); the rows for degrees <= 64 are not used (GF_POLY_LOW above keeps the one-limb mapping
+// what it was).  A wrong entry would make the mapping singular, which make_mapping() reports.
+static const uint8_t GF_POLY_EXP[127][3] = {  // degree 2, 4, ..., 254: x^n + x^a [+ x^b + x^c] + 1
+    {1, 0, 0}, {1, 0, 0}, {1, 0, 0}, {4, 3, 1}, {3, 0, 0}, {3, 0, 0}, {5, 0, 0}, {5, 3, 1},
+    {3, 0, 0}, {3, 0, 0}, {1, 0, 0}, {4, 3, 1}, {4, 3, 1}, {1, 0, 0}, {1, 0, 0}, {7, 3, 2},
+    {7, 0, 0}, {9, 0, 0}, {6, 5, 1}, {5, 4, 3}, {7, 0, 0}, {5, 0, 0}, {1, 0, 0}, {5, 3, 2},
+    {4, 3, 2}, {3, 0, 0}, {9, 0, 0}, {7, 4, 2}, {19, 0, 0}, {1, 0, 0}, {29, 0, 0}, {4, 3, 1},
+    {3, 0, 0}, {9, 0, 0}, {5, 3, 1}, {10, 9, 3}, {35, 0, 0}, {21, 0, 0}, {6, 5, 3}, {9, 4, 2},
+    {8, 3, 1}, {5, 0, 0}, {21, 0, 0}, {7, 6, 2}, {27, 0, 0}, {21, 0, 0}, {21, 0, 0}, {10, 9, 6},
+    {11, 0, 0}, {15, 0, 0}, {29, 0, 0}, {4, 3, 1}, {15, 0, 0}, {17, 0, 0}, {33, 0, 0}, {5, 4, 3},
+    {5, 3, 2}, {4, 2, 1}, {33, 0, 0}, {4, 3, 1}, {6, 2, 1}, {19, 0, 0}, {21, 0, 0}, {7, 2, 1},
+    {3, 0, 0}, {17, 0, 0}, {57, 0, 0}, {5, 3, 2}, {8, 7, 1}, {15, 0, 0}, {21, 0, 0}, {7, 4, 2},
+    {71, 0, 0}, {27, 0, 0}, {53, 0, 0}, {6, 3, 2}, {15, 0, 0}, {9, 0, 0}, {8, 6, 5}, {5, 3, 2},
+    {27, 0, 0}, {10, 8, 7}, {37, 0, 0}, {15, 3, 2}, {11, 0, 0}, {1, 0, 0}, {13, 0, 0}, {11, 3, 2},
+    {31, 0, 0}, {3, 0, 0}, {81, 0, 0}, {9, 8, 7}, {11, 0, 0}, {6, 5, 2}, {8, 7, 6}, {7, 2, 1},
+    {87, 0, 0}, {3, 0, 0}, {9, 0, 0}, {5, 3, 2}, {55, 0, 0}, {27, 0, 0}, {10, 9, 5}, {9, 3, 1},
+    {7, 0, 0}, {105, 0, 0}, {73, 0, 0}, {7, 3, 1}, {11, 0, 0}, {7, 0, 0}, {5, 4, 2}, {9, 8, 3},
+    {10, 7, 3}, {113, 0, 0}, {8, 7, 6}, {9, 4, 2}, {31, 0, 0}, {5, 0, 0}, {73, 0, 0}, {8, 5, 3},
+    {95, 0, 0}, {111, 0, 0}, {11, 2, 1}, {15, 14, 10}, {103, 0, 0}, {15, 0, 0}, {7, 2, 1},
+};
+
+struct Big { uint64_t w[4]; };   // an element of GF(2^n), n <= 254: bit i of the polynomial in w[i / 64]
+static inline Big big_zero() { Big b; b.w[0] = b.w[1] = b.w[2] = b.w[3] = 0; return b; }
+static inline int big_bit(const Big &a, int i) { return (int)((a.w[i >> 6] >> (i & 63)) & 1); }
+static inline void big_xor(Big &a, const Big &b) { for (int t = 0; t < 4; ++t) a.w[t] ^= b.w[t]; }
+static inline Big big_shr2(const Big &a) {
+    Big r;
+    for (int t = 0; t < 4; ++t) r.w[t] = (a.w[t] >> 2) | (t < 3 ? a.w[t + 1] << 62 : 0);
+    return r;
+}
+static inline Big big_mulz(const Big &a, const Big &plow, int n) {  // a * z in GF(2^n)
+    const int top = big_bit(a, n - 1);
+    Big r;
+    for (int t = 3; t >= 0; --t) r.w[t] = (a.w[t] << 1) | (t > 0 ? a.w[t - 1] >> 63 : 0);
+    for (int i = n; i < 256; ++i) r.w[i >> 6] &= ~(1ULL << (i & 63));
+    if (top) big_xor(r, plow);
+    return r;
+}
+static inline Big big_mul(Big a, const Big &b, const Big &plow, int n) {
+    Big r = big_zero();
+    for (int i = 0; i < n; ++i) {
+        if (big_bit(b, i)) big_xor(r, a);
+        a = big_mulz(a, plow, n);
+    }
+    return r;
+}
+
 // The bijective k-mer mapping (IBijectiveFunction / BijectiveKMapping in the reference: a random
-// invertible GF(2) matrix).  Multi-limb keys: M = L * U, random unit triangular factors.
-// One-limb keys (k <= 32): M = multiplication by a random element c of GF(2^2k), a universal
+// invertible GF(2) matrix): M = multiplication by a random element c of GF(2^2k), a universal
 // family whose matrix is dense like a random one -- and because the k-mer window slides by one
 // base (x' = (x >> 2) | b << (2k-2), i.e. x' = (x - low2) / z^2 + b z^(2k-2) as polynomials),
 //     c*x' = (c*x + c*low2) * z^-2 + c*b*z^(2k-2),
-// the scan kernel gets the hash of the next window from the current one with one lookup in the
-// 64-entry table roll[(h & 3) | out << 2 | in << 4] built here.
+// the scan kernels get the hash of the next window from the current one with one lookup in the
+// 64-entry table roll[(h & 3) | out << 2 | in << 4] built here (key_limbs words per entry).
 static int make_mapping(tsx_hip_map *m) {
     const int n = m->p.n, wk = m->p.wk;
     m->rows.assign((size_t)n * wk, 0);
     m->irows.assign((size_t)n * wk, 0);
-    uint64_t st = m->seed, word = 0; int have = 0;
-    auto draw = [&]() { if (!have) { word = splitmix_next(st); have = 64; } const int b = (int)(word & 1); word >>= 1; --have; return b; };
+    uint64_t st = m->seed;
     if (wk == 1) {
         const uint64_t plow = GF_POLY_LOW[n / 2], mask = (n < 64) ? ((1ULL << n) - 1ULL) : ~0ULL;
         uint64_t c = 0;
@@ -211,21 +266,46 @@ static int make_mapping(tsx_hip_map *m) {
             m->roll[idx] = (A[out] >> 2) ^ E[(hb ^ (int)(A[out] & 3ULL)) & 3] ^ C[in];
         }
     } else {
-    // U: unit upper triangular in (row i, column j) terms, as bit masks over input bit positions
-    std::vector<uint64_t> U((size_t)n * wk, 0), Lm((size_t)n * wk, 0);
-    for (int i = 0; i < n; ++i) {
-        rset(&U[(size_t)i * wk], n - 1 - i);
-        for (int j = i + 1; j < n; ++j) if (draw()) rset(&U[(size_t)i * wk], n - 1 - j);
-    }
-    // L: unit lower triangular; Lm[i] = mask over ROW indices j <= i of U that row i of M sums
-    for (int i = 0; i < n; ++i) {
-        rset(&Lm[(size_t)i * wk], i);
-        for (int j = 0; j < i; ++j) if (draw()) rset(&Lm[(size_t)i * wk], j);
-    }
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j)
-            if (rbit(&Lm[(size_t)i * wk], j))
-                for (int t = 0; t < wk; ++t) m->rows[(size_t)i * wk + t] ^= U[(size_t)j * wk + t];
+        const uint8_t *e = GF_POLY_EXP[n / 2 - 1];
+        Big plow = big_zero();
+        plow.w[0] = 1;
+        for (int t = 0; t < 3; ++t) if (e[t]) plow.w[e[t] >> 6] |= 1ULL << (e[t] & 63);
+        Big c = big_zero();
+        bool trivial = true;
+        while (trivial) {   // 0 is not invertible, 1 is the identity
+            for (int t = 0; t < 4; ++t) c.w[t] = splitmix_next(st);
+            for (int i = n; i < 256; ++i) c.w[i >> 6] &= ~(1ULL << (i & 63));
+            trivial = (c.w[0] <= 1 && !c.w[1] && !c.w[2] && !c.w[3]);
+        }
+        // column j of M is c * z^j; rows[i] yields output bit n-1-i
+        Big col = c;
+        for (int j = 0; j < n; ++j) {
+            for (int r = 0; r < n; ++r)
+                if (big_bit(col, r)) rset(&m->rows[(size_t)(n - 1 - r) * wk], j);
+            col = big_mulz(col, plow, n);
+        }
+        Big zinv = big_zero();                                         // z * zinv = 1 (P has constant term 1)
+        for (int t = 0; t < 4; ++t) zinv.w[t] = (plow.w[t] >> 1) | (t < 3 ? plow.w[t + 1] << 63 : 0);
+        zinv.w[(n - 1) >> 6] |= 1ULL << ((n - 1) & 63);
+        const Big zinv2 = big_mul(zinv, zinv, plow, n);
+        Big A[4], C[4], E[4];
+        for (int v = 0; v < 4; ++v) {
+            Big bv = big_zero(); bv.w[0] = (uint64_t)v;
+            A[v] = big_mul(c, bv, plow, n);
+            C[v] = A[v];
+            for (int t = 0; t < n - 2; ++t) C[v] = big_mulz(C[v], plow, n);
+            E[v] = big_zero();
+            if (v & 1) big_xor(E[v], zinv2);
+            if (v & 2) big_xor(E[v], zinv);
+        }
+        m->roll_wide.assign((size_t)64 * wk, 0);
+        for (int idx = 0; idx < 64; ++idx) {
+            const int hb = idx & 3, out = (idx >> 2) & 3, in = (idx >> 4) & 3;
+            Big r = big_shr2(A[out]);
+            big_xor(r, E[(hb ^ (int)(A[out].w[0] & 3ULL)) & 3]);
+            big_xor(r, C[in]);
+            for (int t = 0; t < wk; ++t) m->roll_wide[(size_t)idx * wk + t] = r.w[t];
+        }
     }
     // Inverse by Gauss-Jordan on [A | I], A[r][c] = coefficient of input bit c in output bit r
     // (output bit r is produced by rows[n-1-r]).
@@ -237,7 +317,7 @@ static int make_mapping(tsx_hip_map *m) {
     for (int c = 0; c < n; ++c) {
         int piv = -1;
         for (int r = c; r < n; ++r) if (rbit(&A[(size_t)r * wk], c)) { piv = r; break; }
-        if (piv < 0) return TSX_HIP_EINVAL;  // singular: cannot happen for L*U or for c != 0 with P irreducible
+        if (piv < 0) return TSX_HIP_EINVAL;  // singular: cannot happen for c != 0 with P irreducible
         if (piv != c) for (int t = 0; t < wk; ++t) { std::swap(A[(size_t)piv * wk + t], A[(size_t)c * wk + t]); std::swap(I[(size_t)piv * wk + t], I[(size_t)c * wk + t]); }
         for (int r = 0; r < n; ++r)
             if (r != c && rbit(&A[(size_t)r * wk], c))
@@ -304,8 +384,10 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l, in
     p.k0mask = (p.K0 >= 64) ? ~0ULL : ((1ULL << p.K0) - 1ULL);
     p.lock_bit = lock ? (1ULL << p.K0) : 0ULL;
     p.slot_mask = (1ULL << l) - 1ULL;
-    p.S = std::min(l, 14);           // 2^14 one-limb slots = 128 KiB: one segment fits a CU's LDS
-    if (const char *e = getenv("TSX_HIP_SEG_BITS")) p.S = std::min(l, std::min(14, std::max(8, atoi(e))));
+    // a segment fits a CU's LDS: 128 KiB = 2^14 one-limb slots, 2^13 two-limb, 2^12 three- or four-limb slots
+    const int smax = (W == 1) ? 14 : (W == 2) ? 13 : 12;
+    p.S = std::min(l, smax);
+    if (const char *e = getenv("TSX_HIP_SEG_BITS")) p.S = std::min(l, std::min(smax, std::max(8, atoi(e))));
     p.seg_mask = (1ULL << p.S) - 1ULL;
     const uint64_t maxr = (1ULL << p.R) - 1ULL;
     p.max_reprobes = (uint32_t)std::min<uint64_t>(maxr, p.slot_mask);
@@ -387,12 +469,14 @@ extern "C" int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storage
     HIP_TRY_C(hipMemcpy(m->d_lut, m->lut.data(), m->lut.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY_C(hipMemcpy(m->d_ilut, m->ilut.data(), m->ilut.size() * 8, hipMemcpyHostToDevice));
     p.lut = m->d_lut; p.ilut = m->d_ilut; p.roll = nullptr;
-    if (p.wk == 1) {
-        HIP_TRY_C(hipMalloc((void **)&m->d_roll, sizeof(m->roll)));
-        HIP_TRY_C(hipMemcpy(m->d_roll, m->roll, sizeof(m->roll), hipMemcpyHostToDevice));
+    {
+        const void *src = (p.wk == 1) ? (const void *)m->roll : (const void *)m->roll_wide.data();
+        const size_t bytes = (size_t)64 * p.wk * 8;
+        HIP_TRY_C(hipMalloc((void **)&m->d_roll, bytes));
+        HIP_TRY_C(hipMemcpy(m->d_roll, src, bytes, hipMemcpyHostToDevice));
         p.roll = m->d_roll;
     }
-    rc = tsx_hip_clear(m);
+    rc = clear_impl(m, true);
     if (rc != TSX_HIP_OK) return fail(rc);
     *out = m;
     return TSX_HIP_OK;
@@ -406,6 +490,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
     (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt); (void)hipFree(m->d_small);
+    (void)hipFree(m->d_def_rec); (void)hipFree(m->d_def_cnt); (void)hipFree(m->d_def_n);
     (void)hipFree(m->d_tile); (void)hipFree(m->d_carry); (void)hipFree(m->d_seg);
     (void)hipFree(m->p.seg_dirty); (void)hipFree(m->d_buf[0]); (void)hipFree(m->d_buf[1]); (void)hipFree(m->d_cnt);
     for (int i = 0; i < 2; ++i) {
@@ -426,15 +511,45 @@ extern "C" int tsx_hip_get_layout(const tsx_hip_map *m, tsx_hip_layout *out) {
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_clear(tsx_hip_map *m) {
-    if (!m) return TSX_HIP_EINVAL;
+// Zero the secondary array only when something ever carried into it (it is 1/16 of the table's slots).
+__global__ __launch_bounds__(NT) void sec_clear_kernel(TableParams p, int force) {
+    if (!force && p.stats[ST_CARRY] == 0) return;
+    const uint64_t n2 = (p.sec_mask + 1) / 2;   // uint4 = two slots
+    for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * NT) {
+        reinterpret_cast<uint4 *>(p.sec_keys)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4 *>(p.sec_cnt)[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// full: zero everything now (creation).  Otherwise the table itself is only MARKED clear when the next
+// partitioned build can take care of it (m->fresh): that build writes every segment exactly once -- built,
+// or zeroed when it has no keys -- and every other entry point zeroes the table first (ensure_zeroed).
+static int clear_impl(tsx_hip_map *m, bool full) {
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipMemsetAsync(m->p.table, 0, m->lay.table_bytes, m->stream));
-    HIP_TRY(hipMemsetAsync(m->p.sec_keys, 0, (m->p.sec_mask + 1) * 8, m->stream));
-    HIP_TRY(hipMemsetAsync(m->p.sec_cnt, 0, (m->p.sec_mask + 1) * 8, m->stream));
+    if (full || !can_partition(m)) {
+        HIP_TRY(hipMemsetAsync(m->p.table, 0, m->lay.table_bytes, m->stream));
+        m->fresh = false;
+    } else {
+        m->fresh = true;
+    }
+    hipLaunchKernelGGL(sec_clear_kernel, dim3(m->cus * 4), dim3(NT), 0, m->stream, m->p, full ? 1 : 0);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(m->p.stats, 0, ST_N * sizeof(unsigned long long), m->stream));
     HIP_TRY(hipMemsetAsync(m->p.seg_dirty, 0, (size_t)(m->lay.slots >> m->p.S), m->stream));
     return TSX_HIP_OK;
+}
+
+// The table was cleared lazily and the caller is not a partitioned build: zero it now.
+static int ensure_zeroed(tsx_hip_map *m, hipStream_t st) {
+    if (!m->fresh) return TSX_HIP_OK;
+    HIP_TRY(hipMemsetAsync(m->p.table, 0, m->lay.table_bytes, st));
+    m->fresh = false;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_clear(tsx_hip_map *m) {
+    if (!m) return TSX_HIP_EINVAL;
+    return clear_impl(m, false);
 }
 
 static int read_stats(tsx_hip_map *m, unsigned long long *st) {
@@ -472,21 +587,24 @@ static inline int grid_for(const tsx_hip_map *m, uint64_t work_items, int per_cu
 
 // ---- partitioned path: plan, scratch, launches ------------------------------------
 struct PartPlan {
-    int g;                       // regions of the key log (= scan workgroups, or cuts of a received array)
-    uint64_t log_cap;            // keys per log region
+    int g;                       // regions of the key log (= scan waves, or cuts of a received array)
+    int rw;                      // 64-bit words per record
+    uint64_t log_cap;            // records per log region
     int b1, b2;                  // radix bits of level 1 / level 2 (b2 == 0: one level)
     uint32_t nb1, nb2, nseg, cpr2;
-    uint64_t cap_sub;            // keys per level-2 sub-list
+    uint64_t cap_sub;            // records per level-2 sub-list
     uint32_t hist_nb;            // bins of the scan-side histogram (nb1, or #owners for a sharded scan)
     unsigned long long *c_log, *c_rstart, *c_bstart, *c_bcnt, *c_seg, *d_offs;
     uint32_t *d_hist;
     size_t cnt_need;
 };
 
+static inline int rec_words(int wk) { return wk == 3 ? 4 : wk; }
+
 static bool can_partition(const tsx_hip_map *m) {
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
-    return p.wk == 1 && p.W == 1 && nsegbits >= 1 && nsegbits <= 18;  // two levels of <= 512 lists
+    return nsegbits >= 1 && nsegbits <= 18;  // two levels of <= 512 lists
 }
 
 template <typename T>
@@ -500,13 +618,32 @@ static int grow(hipStream_t st, T *&ptr, size_t &have, size_t need) {
     return TSX_HIP_OK;
 }
 
-// maxrec: upper bound of keys; g: number of source regions; own_log: the keys come from
+// The deferred list of the map (local runs): room for every record of the pass in the worst case (skewed
+// input whose keys all spill); only what is appended is ever touched.
+static int ensure_deferred(tsx_hip_map *m, uint64_t maxrec, hipStream_t st) {
+    const int rw = rec_words(m->p.wk);
+    if (!m->d_def_n) HIP_TRY(hipMalloc((void **)&m->d_def_n, 64));
+    if (maxrec > m->def_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (m->d_def_rec) HIP_TRY(hipFree(m->d_def_rec));
+        if (m->d_def_cnt) HIP_TRY(hipFree(m->d_def_cnt));
+        m->d_def_rec = m->d_def_cnt = nullptr; m->def_cap = 0;
+        const size_t cap = maxrec + maxrec / 8 + 4096;
+        HIP_TRY(hipMalloc((void **)&m->d_def_rec, cap * rw * 8));
+        HIP_TRY(hipMalloc((void **)&m->d_def_cnt, cap * 8));
+        m->def_cap = cap;
+    }
+    return TSX_HIP_OK;
+}
+
+// maxrec: upper bound of records; g: number of source regions; own_log: the records come from
 // this map's scan kernel (needs the log buffer); hist_nb_override: sharded scan.
 static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, uint32_t hist_nb_override,
                           hipStream_t st, PartPlan &pl) {
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
     pl.g = g;
+    pl.rw = rec_words(p.wk);
     pl.nseg = 1u << nsegbits;
     // fan-out per level is capped at 512 (histogram of the scan kernel and ring staging live in LDS)
     pl.b1 = std::min(9, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
@@ -520,12 +657,12 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.cpr2 = pl.b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / pl.nb1)) : 1;
     if (pl.b2) if (const char *e = getenv("TSX_HIP_CPR2")) pl.cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
     const uint64_t per_sub = maxrec / pl.nseg / pl.cpr2;
-    // multiple of 16 keys: every sub-list starts on a 128-B line
+    // multiple of 16 records: every sub-list starts on a 128-B line
     pl.cap_sub = (per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64 + 15) & ~15ULL;
     // buffer 0: key log, later the segment sub-lists of a two-level split; buffer 1: packed level-1 output
-    const uint64_t keys_cap = own_log ? (uint64_t)g * pl.log_cap : maxrec;
-    const size_t need0 = std::max<uint64_t>(own_log ? keys_cap : 0, pl.b2 ? (uint64_t)pl.nseg * pl.cpr2 * pl.cap_sub : 0) * 8;
-    const size_t need1 = keys_cap * 8;
+    const uint64_t rec_cap = own_log ? (uint64_t)g * pl.log_cap : maxrec;
+    const size_t need0 = std::max<uint64_t>(own_log ? rec_cap : 0, pl.b2 ? (uint64_t)pl.nseg * pl.cpr2 * pl.cap_sub : 0) * 8 * pl.rw;
+    const size_t need1 = rec_cap * 8 * pl.rw;
     int rc = grow(st, m->d_buf[0], m->buf_bytes[0], need0);
     if (rc != TSX_HIP_OK) return rc;
     rc = grow(st, m->d_buf[1], m->buf_bytes[1], need1);
@@ -547,23 +684,45 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.d_hist = reinterpret_cast<uint32_t *>(pl.d_offs + mat);
     HIP_TRY(hipMemsetAsync(m->d_cnt, 0, pl.cnt_need * 8, st));
     if (!m->attr_done) {   // per map, hence per device: the attribute belongs to the device's copy of the kernel
-        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 << 10));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10));
+        const int big = 150 << 10, seg = 128 << 10;
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         m->attr_done = true;
     }
     return TSX_HIP_OK;
 }
 
-// Radix level 1 (+ level 2) and the segment build.  Source keys: g regions of `src`,
-// either src_cap apart with fills c_log (a key log) or at region_start/c_log (cuts of a
-// packed array); pl.d_hist must hold their level-1 histogram.
+// Launch with the record width as a compile-time constant.
+#define DISPATCH_RW(rw, CALL)                        \
+    switch (rw) {                                    \
+        case 1: { constexpr int RWV = 1; CALL; } break; \
+        case 2: { constexpr int RWV = 2; CALL; } break; \
+        default: { constexpr int RWV = 4; CALL; } break; \
+    }
+
+// Radix level 1 (+ level 2), the segment build, then everything that waited for the build (overflow
+// queues, deferred list).  Source records: g regions of `src`, either src_cap apart with fills c_log (a
+// key log) or at region_start/c_log (cuts of a packed array); pl.d_hist must hold their level-1
+// histogram.  The caller has made room in the map's deferred list (ensure_deferred) and reset its
+// counter before the first kernel that may append to it.
 static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_t *src,
                                const unsigned long long *region_start, uint64_t src_cap, hipStream_t st,
                                hipEvent_t *ev = nullptr) {
+    TableParams pp = m->p;
     const TableParams &p = m->p;
-    // ring depth: PART_FLUSH-1 keys may stay behind a flush, plus one batch of arrivals (mean = batch / nb)
+    pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
+    const int rw = pl.rw;
+    // ring depth in words: PART_FLUSH-1 words may stay behind a flush, plus one batch of arrivals (mean = batch / nb)
     auto ring_bits = [](uint32_t nb) {
-        const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_RPT / nb);
+        const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_WPT / nb);
         uint32_t bits = 4;
         while ((1u << bits) < PART_FLUSH + 2 * mean && bits < 6) ++bits;
         return bits;
@@ -574,11 +733,11 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, pl.nb1, pl.c_bstart, pl.c_bcnt);
     {   // level 1: every region -> packed array ordered by the top b1 bits of the home slot
         const uint32_t bits = ring_bits(pl.nb1);
-        hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st, m->p, src,
-                           region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u, m->d_buf[1],
-                           (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
+        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st,
+                           pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,
+                           m->d_buf[1], (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
-                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u);
+                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u));
         HIP_TRY(hipGetLastError());
     }
     if (ev) HIP_TRY(hipEventRecord(ev[4], st));
@@ -586,37 +745,57 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
     uint64_t lists_cap = 0;
     uint32_t pieces = 1;
+    uint32_t nq2 = 0;
     if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
         const uint32_t bits = ring_bits(pl.nb2);
-        const uint32_t nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup
-        if ((size_t)nq2 > m->ovq_queues) {
+        nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup
+        if ((size_t)nq2 * rw > m->ovq_queues) {
             HIP_TRY(hipStreamSynchronize(st));
             if (m->d_ovq) HIP_TRY(hipFree(m->d_ovq));
             if (m->d_ovq_cnt) HIP_TRY(hipFree(m->d_ovq_cnt));
             m->d_ovq = nullptr; m->d_ovq_cnt = nullptr; m->ovq_queues = 0;
-            HIP_TRY(hipMalloc((void **)&m->d_ovq, (size_t)nq2 * OVQ_CAP * 8));
+            HIP_TRY(hipMalloc((void **)&m->d_ovq, (size_t)nq2 * OVQ_CAP * 8 * rw));
             HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, (size_t)nq2 * 4));
-            m->ovq_queues = nq2;
+            m->ovq_queues = (size_t)nq2 * rw;
         }
-        hipLaunchKernelGGL(partition_ring_kernel, dim3(pl.nb1 * pl.cpr2), dim3(PART_NT), part_lds(pl.nb2, bits), st, m->p,
-                           (const uint64_t *)m->d_buf[1], (const unsigned long long *)pl.c_bstart,
-                           (const unsigned long long *)pl.c_bcnt, (uint64_t)0, pl.nb1, pl.cpr2, m->d_buf[0],
-                           (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, pl.c_seg,
-                           pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg, m->d_ovq, m->d_ovq_cnt, OVQ_CAP);
-        HIP_TRY(hipGetLastError());
-        // ordinary keys that found their sub-list filled up by a hot key: inserted now, by the whole chip
-        hipLaunchKernelGGL(overflow_insert_kernel, dim3(std::min<uint32_t>(nq2, (uint32_t)m->cus * 8)), dim3(PART_NT), 0, st,
-                           m->p, (const uint64_t *)m->d_ovq, (const uint32_t *)m->d_ovq_cnt, OVQ_CAP, nq2);
+        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(PART_NT),
+                           part_lds(pl.nb2, bits), st, pp, (const uint64_t *)m->d_buf[1],
+                           (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
+                           pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
+                           (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg,
+                           m->d_ovq, m->d_ovq_cnt, OVQ_CAP));
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
     if (ev) HIP_TRY(hipEventRecord(ev[5], st));
+    const int fresh = m->fresh ? 1 : 0;
     if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
         const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 16);
         int bnt = 1024;
         if (const char *e = getenv("TSX_HIP_BUILD_NT")) bnt = std::min(1024, std::max(64, atoi(e) & ~63));
-        hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), (size_t)8 << p.S, st, m->p, lists, lists_start,
-                           lists_cnt, lists_cap, pieces, pl.nseg, m->dbg);
+        const size_t seg_bytes = ((size_t)8 << p.S) * p.W;
+        if (p.wk == 1 && p.W == 1) {
+            hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
+                               lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
+        } else {
+            DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_kernel<WKV>), dim3(gb), dim3(bnt), seg_bytes, st, pp,
+                                              lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh));
+        }
+        HIP_TRY(hipGetLastError());
+        m->fresh = false;   // every segment has been written: built, or zeroed
+    }
+    // Records that found their sub-list filled up by a hot key, and the deferred list: inserted now, by the
+    // whole chip, into a table whose segments are all in place.
+    if (nq2 && !(m->dbg & 1)) {
+        DISPATCH_WK(m, hipLaunchKernelGGL((overflow_insert_kernel<WKV>), dim3(std::min<uint32_t>(nq2, (uint32_t)m->cus * 8)),
+                                          dim3(PART_NT), 0, st, pp, (const uint64_t *)m->d_ovq,
+                                          (const uint32_t *)m->d_ovq_cnt, OVQ_CAP, nq2));
+        HIP_TRY(hipGetLastError());
+    }
+    if (!(m->dbg & 1)) {
+        DISPATCH_WK(m, hipLaunchKernelGGL((deferred_insert_kernel<WKV>), dim3(m->cus * 2), dim3(PART_NT), 0, st, pp,
+                                          (const uint64_t *)m->d_def_rec, (const uint64_t *)m->d_def_cnt,
+                                          (const unsigned long long *)m->d_def_n, (uint64_t)0, (uint64_t)m->def_cap));
         HIP_TRY(hipGetLastError());
     }
     return TSX_HIP_OK;
@@ -677,6 +856,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const TableParams &p = m->p;
     const bool use_part = shard_send || (can_partition(m) && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes)));
     if (!use_part) {
+        int rcz = ensure_zeroed(m, st);
+        if (rcz != TSX_HIP_OK) return rcz;
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
                                           own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
         HIP_TRY(hipGetLastError());
@@ -686,17 +867,42 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
 
     const uint64_t maxrec = own_end / 2 + 65536;
     const uint32_t nown = 1u << (p.lg - p.l);
-    // the scan kernel of this path keeps one log region per WAVE
-    const int gs = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * SCAN_WG_PER_CU);
+    // the scan kernels of this path keep one log region per WAVE
+    const int scan_wgs = (p.wk == 1) ? SCAN_WG_PER_CU : 2;
+    const int gs = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * scan_wgs);
     const int greg = gs * (NT / 64);
     PartPlan pl;
     int rc = plan_partition(m, maxrec, greg, true, shard_send ? nown : 0, st, pl);
     if (rc != TSX_HIP_OK) return rc;
+    // what cannot take the fast route: the caller's hot list (sharded scan), else the map's deferred list
+    TableParams pp = m->p;
+    if (shard_send) {
+        pp.defer = DeferList{hot.keys, hot.cnts, hot.n, hot.cap};
+    } else {
+        rc = ensure_deferred(m, maxrec, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_def_n, 0, 8, st));
+        pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
+    }
     // scan -> key log + histogram by level-1 bucket, or by owner GPU for a sharded scan
-    hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, m->p, d_text, n, own_end, head_open,
-                       (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
-                       shard_send ? nown : pl.nb1, (uint32_t)(shard_send ? p.l : p.l - pl.b1), hot.keys, hot.cnts, hot.cap,
-                       hot.n);
+    const uint32_t hist_nb = shard_send ? nown : pl.nb1, hist_shift = (uint32_t)(shard_send ? p.l : p.l - pl.b1);
+    if (p.wk == 1) {
+        hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
+                           (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
+                           hist_nb, hist_shift);
+    } else {
+        switch (p.wk) {
+            case 2: hipLaunchKernelGGL((scan_log_wide_kernel<2>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
+                                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
+                                       pl.c_log, pl.d_hist, hist_nb, hist_shift); break;
+            case 3: hipLaunchKernelGGL((scan_log_wide_kernel<3>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
+                                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
+                                       pl.c_log, pl.d_hist, hist_nb, hist_shift); break;
+            default: hipLaunchKernelGGL((scan_log_wide_kernel<4>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
+                                        head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
+                                        pl.c_log, pl.d_hist, hist_nb, hist_shift); break;
+        }
+    }
     HIP_TRY(hipGetLastError());
     if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
     if (shard_send) {
@@ -780,6 +986,8 @@ extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, 
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
     if (!can_partition(m)) {  // tiny tables: plain atomic inserts of the hashed keys
+        int rcz = ensure_zeroed(m, st);
+        if (rcz != TSX_HIP_OK) return rcz;
         const int grid = grid_for(m, n_keys, 8);
         hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
                            (const uint64_t *)nullptr, (uint64_t)n_keys, key_sum);
@@ -791,6 +999,9 @@ extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, 
     PartPlan pl;
     int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl);
     if (rc != TSX_HIP_OK) return rc;
+    rc = ensure_deferred(m, n_keys + 65536, st);
+    if (rc != TSX_HIP_OK) return rc;
+    HIP_TRY(hipMemsetAsync(m->d_def_n, 0, 8, st));
     hipEvent_t *ev = nullptr;
     if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + 7 <= m->ev_used) {
         ev = &m->ev[(size_t)m->ev_open.front()];
@@ -813,6 +1024,8 @@ extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, c
     if (n == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
+    int rcz = ensure_zeroed(m, st);
+    if (rcz != TSX_HIP_OK) return rcz;
     const int grid = grid_for(m, n, 8);
     hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
                        (const uint64_t *)dev_counts, (uint64_t)n, (unsigned long long *)nullptr);
@@ -976,6 +1189,8 @@ extern "C" int tsx_hip_add_kmers_device(tsx_hip_map *m, const void *dev_kmers, c
     if (n == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
+    int rcz = ensure_zeroed(m, st);
+    if (rcz != TSX_HIP_OK) return rcz;
     const int grid = grid_for(m, n, 8);
     DISPATCH_WK(m, hipLaunchKernelGGL((add_kmers_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p,
                                       (const uint64_t *)dev_kmers, (const uint64_t *)dev_counts, (uint64_t)n));
@@ -1011,6 +1226,8 @@ extern "C" int tsx_hip_get_counts_device(tsx_hip_map *m, const void *dev_kmers, 
     if (n == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
+    int rcz = ensure_zeroed(m, st);
+    if (rcz != TSX_HIP_OK) return rcz;
     const int grid = grid_for(m, n, 8);
     DISPATCH_WK(m, hipLaunchKernelGGL((get_counts_kernel<WKV>), dim3(grid), dim3(NT), 0, st, m->p,
                                       (const uint64_t *)dev_kmers, (uint64_t)n, (uint64_t *)dev_counts_out,
@@ -1026,6 +1243,8 @@ static int lookup_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t
     if (!m || ((!kmers || !counts_out) && n)) return TSX_HIP_EINVAL;
     if (n == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
+    int rcz = ensure_zeroed(m, m->stream);
+    if (rcz != TSX_HIP_OK) return rcz;
     const size_t wk = (size_t)m->p.wk, kb = n * wk * 8;
     uint64_t *dk = nullptr, *dc = nullptr, *dp = nullptr;
     const bool small = n <= SMALL_LOOKUP;
@@ -1062,6 +1281,8 @@ extern "C" int tsx_hip_kmer_starts_host(tsx_hip_map *m, uint8_t *bits_out, size_
     if (!m || !bits_out || nbytes * 8 < m->lay.slots) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
     const uint64_t nb = (m->lay.slots + 7) / 8;
+    int rcz = ensure_zeroed(m, m->stream);
+    if (rcz != TSX_HIP_OK) return rcz;
     uint8_t *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, nb));
     hipLaunchKernelGGL(kmer_starts_kernel, dim3(grid_for(m, nb, 8)), dim3(NT), 0, m->stream, m->p, d, nb);
@@ -1080,6 +1301,8 @@ extern "C" int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, si
 extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
     if (!m || !out) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
+    int rcz = ensure_zeroed(m, m->stream);
+    if (rcz != TSX_HIP_OK) return rcz;
     HIP_TRY(hipMemsetAsync(m->p.stats + ST_SCRATCH, 0, 2 * sizeof(unsigned long long), m->stream));
     HIP_TRY(hipMemsetAsync(m->p.stats + ST_SCRATCH3, 0, sizeof(unsigned long long), m->stream));
     const int grid = grid_for(m, m->lay.slots, 8);
@@ -1107,6 +1330,8 @@ static int dump_slots(tsx_hip_map *m, int nranks, uint64_t slot_lo, uint64_t slo
     if (slot_lo > slot_hi || slot_hi > m->lay.slots) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
+    int rcz = ensure_zeroed(m, st);
+    if (rcz != TSX_HIP_OK) return rcz;
     const int grid = grid_for(m, std::max<uint64_t>(1, slot_hi - slot_lo), 8);
     unsigned long long *seg = m->d_seg;
     HIP_TRY(hipMemsetAsync(seg, 0, 64 * sizeof(unsigned long long), st));
