@@ -36,7 +36,10 @@ public:
     // mirrors TSXHashMapCAS(iL, iStorageBits, iK, iThreads) (TSXHashMapCAS.h:239-245).  The base
     // class keeps its own (host) array and k-mer-start bitmap of 2^iL places; only the bitmap is used.
     TSXHashMapHIP(uint8_t iL, uint32_t iStorageBits, uint16_t iK, uint8_t iThreads = 0)
-        : TSXHashMap(iL, iStorageBits, iK), m_iThreads(iThreads) {
+        : TSXHashMap(iL, iStorageBits, iK) {
+        // one MemoryPool slice per OpenMP thread (TSXHashMap.h:741-746): countKMers' tasks allocate their
+        // UBigInts from the pool of the thread they run on
+        this->setThreads(iThreads ? iThreads : 1);
         int rc = tsx_hip_create(&m_pDev, iK, iL, (int)iStorageBits, /*overflow_l=*/0,
                                 /*hash_seed=*/(uint64_t)time(NULL), /*device=*/0);
         if (rc != TSX_HIP_OK) throw TSXException(tsx_hip_strerror(rc));
@@ -131,7 +134,6 @@ private:
     std::mutex m_oLock;
     std::vector<uint64_t> m_vPending;
     size_t m_iLimbs = 1;
-    uint8_t m_iThreads;
     uint64_t m_aLast[4] = {0, 0, 0, 0}, m_iLastCount = 0, m_iLastSlot = 0;
     bool m_bLast = false;
 };
