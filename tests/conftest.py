@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_gpu_first():
+    """On a GPU box bring torch's device context up before the first test: the tests mix torch tensors (device
+    buffers, collectives) with the HIP library, and torch failed to find the GPU once ("No HIP GPUs are
+    available") when its lazy initialisation came after ~90 tests of the library alone."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda:0")
+            torch.cuda.synchronize()
+    except Exception:  # noqa: BLE001 -- CPU-only box, or torch without a device: the gpu tests will say so themselves
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_fastq():
     """data/small_t7.1000.fastq from the reference (a data fixture, 250 reads)."""

@@ -623,6 +623,206 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
     }
 }
 
+// ---- build, second form (one-limb keys and slots): wave-level key streams --------------------------
+// build_segments_kernel above gives every LANE a private stream of keys with a register FIFO of loads in
+// flight.  Its disassembly shows what that costs: the FIFO advances by register moves, a move of a load's
+// destination needs that load finished, the wave's load counter is in order -- so every round in which ANY
+// lane places a key (nearly all of them) waits for the load issued one round earlier: the loop runs at one
+// HBM latency per round (~1000 cycles for ~40 instructions), and a lane's 12 keys take 22 rounds on
+// average, 40 for the slowest lane of the workgroup.
+// Here a WAVE owns a stream: batches of 64 consecutive keys, one key per lane, all of a segment's batches
+// loaded up front by coalesced 512-byte reads into registers (BK batches per wave and pass), and the NEXT
+// segment's lists are pulled into L2 meanwhile: every lane loads ONE dword of one 128-byte line of them (1024
+// lanes = 128 KiB of lists) into a register nobody needs before the next segment starts, so the loop itself
+// never waits for HBM.  (LDS-DMA into a dump area would cost no register at all, but the compiler orders
+// every later LDS read behind a pending LDS-DMA with s_waitcnt vmcnt(0), which makes it synchronous.)  A lane that has placed its key takes the next unconsumed key of the wave's stream: a ballot and a
+// prefix count give it the stream position, ds_bpermute fetches the key from the lane that holds it (the
+// current or the next batch register).  All lanes stay busy until the stream runs dry; the tail is one key's
+// probe chain, not the sum of a lane's.
+constexpr int BK = 16;   // batches (of 64 keys) a wave holds in registers per pass
+
+__device__ __forceinline__ uint64_t pick_batch(const uint64_t (&B)[BK], uint32_t j) {   // j is wave-uniform
+    uint64_t v = 0;
+    switch (j) {
+        case 0: v = B[0]; break;   case 1: v = B[1]; break;   case 2: v = B[2]; break;   case 3: v = B[3]; break;
+        case 4: v = B[4]; break;   case 5: v = B[5]; break;   case 6: v = B[6]; break;   case 7: v = B[7]; break;
+        case 8: v = B[8]; break;   case 9: v = B[9]; break;   case 10: v = B[10]; break; case 11: v = B[11]; break;
+        case 12: v = B[12]; break; case 13: v = B[13]; break; case 14: v = B[14]; break; case 15: v = B[15]; break;
+        default: break;
+    }
+    return v;
+}
+
+// The batches of pass `pass` of one wave: batch j of the pass is batch t = wi + (pass*BK + j)*nw of the
+// wave group's list (`mine` keys at `base`); lane L holds key t*64 + L.
+__device__ __forceinline__ void load_batches(const uint64_t *base, uint32_t mine, uint32_t wi, uint32_t nw,
+                                             uint32_t pass, uint32_t lane, uint64_t (&B)[BK]) {
+#pragma unroll
+    for (int j = 0; j < BK; ++j) {
+        const uint32_t idx = (wi + (pass * BK + (uint32_t)j) * nw) * 64u + lane;
+        B[j] = (idx < mine) ? base[idx] : 0ULL;
+    }
+}
+// keys of the wave's stream in that pass
+__device__ __forceinline__ uint32_t pass_total(uint32_t mine, uint32_t wi, uint32_t nw, uint32_t pass) {
+    uint32_t tot = 0;
+    for (uint32_t j = 0; j < (uint32_t)BK; ++j) {
+        const uint32_t first = (wi + (pass * BK + j) * nw) * 64u;
+        tot += (first < mine) ? min(64u, mine - first) : 0u;
+    }
+    return tot;
+}
+
+__global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams p, const uint64_t *lists,
+                                                                     const unsigned long long *list_start,
+                                                                     const unsigned long long *list_cnt,
+                                                                     uint64_t list_cap, uint32_t pieces, uint32_t nseg,
+                                                                     int dbg, int fresh) {
+    extern __shared__ uint64_t s_seg[];  // 2^S slots
+    const uint32_t nslots = 1u << p.S;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t npieces = list_start ? 1u : pieces;
+    const uint32_t nw = (nt / 64u) / npieces;          // waves per list (pieces is a power of two <= 8)
+    const uint32_t grp = wave / nw, wi = wave % nw;
+    const uint32_t smask = (uint32_t)p.seg_mask;
+    const uint64_t k0mask = p.k0mask;
+    const uint32_t maxr = p.max_reprobes;
+    const uint64_t one = 1ULL << p.cshift;
+
+    // this wave's list of segment `seg`: where it starts and how many keys it holds
+    auto my_list = [&](uint32_t seg, const uint64_t *&base) -> uint32_t {
+        if (list_start) { base = lists + (uint64_t)list_start[seg]; return (uint32_t)list_cnt[seg]; }
+        base = lists + ((uint64_t)seg * pieces + grp) * list_cap;
+        return (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + grp], list_cap);
+    };
+    auto seg_keys = [&](uint32_t seg) -> uint64_t {
+        if (list_start) return (uint64_t)list_cnt[seg];
+        uint64_t n = 0;
+        for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
+        return n;
+    };
+
+    uint64_t B[BK];
+    uint32_t pf = 0;   // the dword this lane prefetched for the next segment
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        asm volatile("" ::"v"(pf));   // the prefetch is 'used' here, a segment after it was issued
+        const uint64_t n = seg_keys(seg);
+        uint64_t *slots = p.table + ((uint64_t)seg << p.S);
+        if (n == 0) {
+            if (fresh) {   // nothing to insert, but the stale slots must go
+                for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
+                    *reinterpret_cast<uint4 *>(&slots[i]) = make_uint4(0, 0, 0, 0);
+                if (tid == 0) p.seg_dirty[seg] = 0;
+            }
+            continue;
+        }
+        const bool dirty = !fresh && p.seg_dirty[seg] != 0;
+        const uint64_t *base;
+        const uint32_t mine = my_list(seg, base);
+        load_batches(base, mine, wi, nw, 0, lane, B);   // (L2 hits: the previous segment's pass prefetched them)
+        lds_barrier();  // previous segment fully written out
+        if (dirty) {
+            for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
+        } else {
+            for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
+        }
+        lds_barrier();
+        const uint32_t npass = ((mine + 63u) / 64u + nw * BK - 1u) / (nw * BK);   // wave-group uniform
+        for (uint32_t pass = 0; pass < npass && !(dbg & 2); ++pass) {
+            if (pass > 0) load_batches(base, mine, wi, nw, pass, lane, B);   // long lists only: not prefetched
+            const uint32_t total = pass_total(mine, wi, nw, pass);
+            uint32_t cb = 0, off = 0, taken = 0;    // wave-uniform: current batch, keys consumed of it, keys consumed in all
+            // the batches must have arrived: the one wait for loads of this segment, spelled out so that the
+            // prefetch below is issued behind it (and stays in flight), not in front of it
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            uint64_t cur = B[0], nxt = B[1];
+            if (pass == 0) {
+                // the next segment's lists start towards L2 now and stay in flight while this segment is
+                // inserted and written out: lane L of the lanes that share a list touches line L of it
+                const uint32_t nseg2 = seg + gridDim.x;
+                if (nseg2 < nseg) {
+                    const uint64_t *base2;
+                    const uint32_t mine2 = my_list(nseg2, base2);
+                    const uint32_t line = (wi * 64u + lane) * 16u;             // first key of this lane's line
+                    if (line < mine2) pf = *reinterpret_cast<const uint32_t *>(base2 + line);
+                }
+            }
+            bool busy = false;
+            uint64_t e0 = 0;
+            uint32_t i = 1, q = 0;
+            while (true) {
+                // ---- hand the next keys of the stream to the lanes that have none
+                if (taken < total) {
+                    const unsigned long long nm = __ballot(!busy);
+                    if (nm) {
+                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+                        const uint32_t pp = off + pre;            // position relative to the current batch: 0..126
+                        const int addr = (int)((pp & 63u) << 2);
+                        // every lane takes part: ds_bpermute returns 0 for a source lane that is switched off
+                        uint32_t klo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)cur);
+                        uint32_t khi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(cur >> 32));
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(nm);
+                        if (off + cnt > 64u) {                    // wave-uniform: some lanes reach into the next batch
+                            const uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)nxt);
+                            const uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(nxt >> 32));
+                            klo = (pp >= 64u) ? nlo : klo;
+                            khi = (pp >= 64u) ? nhi : khi;
+                        }
+                        if (!busy && taken + pre < total) {
+                            const uint64_t key = (uint64_t)klo | ((uint64_t)khi << 32);
+                            busy = true;
+                            i = 1;
+                            q = ((uint32_t)key + 1u) & smask;                     // q_1 = q_0 + 1
+                            e0 = ((key >> p.lg) << p.R) & k0mask;                 // split_key for WK = 1
+                        }
+                        const uint32_t got = min(cnt, total - taken);
+                        taken += got;
+                        off += got;
+                        if (off >= 64u) {
+                            off -= 64u;
+                            ++cb;
+                            cur = nxt;
+                            nxt = pick_batch(B, cb + 1u);
+                        }
+                    }
+                }
+                if (__ballot(busy) == 0ULL) break;   // stream dry and every key placed
+                // ---- one probe for every lane that holds a key
+                if (busy) {
+                    const uint64_t key0 = e0 | i;
+                    const unsigned long long old =
+                        atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
+                    bool placed = (old == 0ULL);
+                    if (!placed && (old & k0mask) == key0) {
+                        const unsigned long long prev =
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[q]), (unsigned long long)one);
+                        const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
+                        if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
+                        placed = true;
+                    }
+                    if (!placed && i >= maxr) {
+                        atomicAdd(&p.stats[ST_FAIL], 1ULL);
+                        placed = true;
+                    }
+                    ++i;
+                    q = (q + i) & smask;
+                    busy = !placed;
+                }
+            }
+        }
+        lds_barrier();
+        if (!(dbg & 4))
+            for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);
+        if (tid == 0) p.seg_dirty[seg] = 1;
+    }
+}
+
 // The same for multi-limb keys and/or multi-limb slots (k > 32, or wide counters): records of RW words,
 // slots of W words in LDS (AoS, like the table).  Limb 0 is claimed by a 64-bit LDS CAS with the LOCK bit
 // set, the claimant writes limbs 1..W-1 and then stores limb 0 without LOCK -- the protocol of insert_key

@@ -655,6 +655,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     if (const char *e = getenv("TSX_HIP_LOG_CAP")) pl.log_cap = even(std::max(16, atoi(e)));  // tests: force region overflow
     // level 2 runs cpr2 workgroups per level-1 bucket; each owns one sub-list per segment
     pl.cpr2 = pl.b2 ? (uint32_t)std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / pl.nb1)) : 1;
+    while (pl.cpr2 & (pl.cpr2 - 1)) pl.cpr2 &= pl.cpr2 - 1;   // a power of two: the build gives every sub-list 16/cpr2 waves
     if (pl.b2) if (const char *e = getenv("TSX_HIP_CPR2")) pl.cpr2 = (uint32_t)std::min(8, std::max(1, atoi(e)));
     const uint64_t per_sub = maxrec / pl.nseg / pl.cpr2;
     // multiple of 16 records: every sub-list starts on a 128-B line
@@ -689,6 +690,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
@@ -774,7 +776,12 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         int bnt = 1024;
         if (const char *e = getenv("TSX_HIP_BUILD_NT")) bnt = std::min(1024, std::max(64, atoi(e) & ~63));
         const size_t seg_bytes = ((size_t)8 << p.S) * p.W;
-        if (p.wk == 1 && p.W == 1) {
+        static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
+        if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
+        if (p.wk == 1 && p.W == 1 && build_v == 2) {
+            hipLaunchKernelGGL(build_segments_stream_kernel, dim3(gb), dim3(1024), seg_bytes, st, pp, lists, lists_start,
+                               lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
+        } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
                                lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
         } else {
