@@ -31,7 +31,12 @@ enum StatIdx {
     ST_SCRATCH2 = 6,
     ST_FALLBACK = 7,   // keys the partitioned path handed to insert_key (a list or log region was full)
     ST_SCRATCH3 = 8,   // reduction: sum of all counts
-    ST_N = 9
+    ST_DBG0 = 9,       // diagnostic builds (TSX_HIP_DEBUG bit 4): wave-rounds of the segment build ...
+    ST_DBG1 = 10,      // ... shader cycles inside its insert loop, summed over waves
+    ST_DBG2 = 11,      // ... lanes that probed, summed over rounds
+    ST_DBG3 = 12,      // ... rounds with fewer than 16 probing lanes
+    ST_DBG4 = 13,      // ... cycles of those rounds
+    ST_N = 16
 };
 
 // Keys that cannot take the fast route of the partitioned path (a full log region, a hot k-mer merged on
@@ -81,6 +86,16 @@ __device__ __attribute__((noinline)) void defer_append(const TableParams *pk, co
     if (at < pk->defer.cap) {
 #pragma unroll
         for (int t = 0; t < RW; ++t) pk->defer.rec[at * RW + t] = r[t];
+        pk->defer.cnt[at] = d;
+    } else {
+        atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
+    }
+}
+// One-word records by value (a pointer argument would force the caller's key into scratch memory).
+__device__ __attribute__((noinline)) void defer_append1(const TableParams *pk, uint64_t key, uint64_t d) {
+    const unsigned long long at = atomicAdd(pk->defer.n, 1ULL);
+    if (at < pk->defer.cap) {
+        pk->defer.rec[at] = key;
         pk->defer.cnt[at] = d;
     } else {
         atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     auto side_insert = [&](uint64_t hkey, uint64_t d) {
         if (dbg & 1) return;
-        defer_append<1>(pk, &hkey, d);
+        defer_append1(pk, hkey, d);
     };
 
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

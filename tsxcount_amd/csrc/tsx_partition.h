@@ -635,10 +635,14 @@ __global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, con
 // segment's lists are pulled into L2 meanwhile: every lane loads ONE dword of one 128-byte line of them (1024
 // lanes = 128 KiB of lists) into a register nobody needs before the next segment starts, so the loop itself
 // never waits for HBM.  (LDS-DMA into a dump area would cost no register at all, but the compiler orders
-// every later LDS read behind a pending LDS-DMA with s_waitcnt vmcnt(0), which makes it synchronous.)  A lane that has placed its key takes the next unconsumed key of the wave's stream: a ballot and a
-// prefix count give it the stream position, ds_bpermute fetches the key from the lane that holds it (the
-// current or the next batch register).  All lanes stay busy until the stream runs dry; the tail is one key's
-// probe chain, not the sum of a lane's.
+// every later LDS read behind a pending LDS-DMA with s_waitcnt vmcnt(0), which makes it synchronous.)
+// A lane that has placed its key takes the next unconsumed key of the wave's stream: a ballot and a
+// prefix count give it the stream position.  The two batches the wave is consuming sit in a 1 KiB ring of
+// the wave's own behind the segment (written from the batch registers, one ds_write_b64 per 64 keys), so the
+// lanes that ask for keys in a round read CONSECUTIVE 8-byte words: one conflict-free ds_read_b64.  (Fetching
+// straight from the batch registers with ds_bpermute measured slower than the per-lane FIFO: a
+// ds_bpermute_b32 occupies the LDS pipe for ~16 cycles, four of them per round and wave saturate it.)
+// All lanes stay busy until the stream runs dry; the tail is one key's probe chain, not the sum of a lane's.
 constexpr int BK = 16;   // batches (of 64 keys) a wave holds in registers per pass
 
 __device__ __forceinline__ uint64_t pick_batch(const uint64_t (&B)[BK], uint32_t j) {   // j is wave-uniform
@@ -673,15 +677,24 @@ __device__ __forceinline__ uint32_t pass_total(uint32_t mine, uint32_t wi, uint3
     return tot;
 }
 
+template <bool DIAG>   // DIAG: the ablation / diagnostic switches of TSX_HIP_DEBUG are compiled in
 __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams p, const uint64_t *lists,
                                                                      const unsigned long long *list_start,
                                                                      const unsigned long long *list_cnt,
                                                                      uint64_t list_cap, uint32_t pieces, uint32_t nseg,
-                                                                     int dbg, int fresh) {
-    extern __shared__ uint64_t s_seg[];  // 2^S slots
+                                                                     int dbg_arg, int fresh) {
+    const int dbg = DIAG ? dbg_arg : 0;
+    extern __shared__ uint64_t s_seg[];  // 2^S slots, then four batches of 64 keys per wave
     const uint32_t nslots = 1u << p.S;
     const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t *ring = s_seg + nslots + wave * 256u;   // batch b of the wave's stream sits in ring[(b & 3) * 64 ..]
+    // The two shift amounts of split_key live in VECTOR registers on purpose: the kernel is short of scalar
+    // registers, and the compiler otherwise re-reads them from the kernel-argument segment inside the probe
+    // loop -- two dependent scalar loads (s_load + s_waitcnt lgkmcnt(0)) in every round.
+    uint32_t sh_lg, sh_r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(sh_lg) : "s"(p.lg));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(sh_r) : "s"(p.R));
     const uint32_t npieces = list_start ? 1u : pieces;
     const uint32_t nw = (nt / 64u) / npieces;          // waves per list (pieces is a power of two <= 8)
     const uint32_t grp = wave / nw, wi = wave % nw;
@@ -735,11 +748,15 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
             if (pass > 0) load_batches(base, mine, wi, nw, pass, lane, B);   // long lists only: not prefetched
             const uint32_t total = pass_total(mine, wi, nw, pass);
             uint32_t cb = 0, off = 0, taken = 0;    // wave-uniform: current batch, keys consumed of it, keys consumed in all
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads of the ring are done
             // the batches must have arrived: the one wait for loads of this segment, spelled out so that the
             // prefetch below is issued behind it (and stays in flight), not in front of it
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
-            uint64_t cur = B[0], nxt = B[1];
+            ring[lane] = B[0];
+            ring[64u + lane] = B[1];
+            ring[128u + lane] = B[2];
+            ring[192u + lane] = B[3];
             if (pass == 0) {
                 // the next segment's lists start towards L2 now and stay in flight while this segment is
                 // inserted and written out: lane L of the lanes that share a list touches line L of it
@@ -751,49 +768,43 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                     if (line < mine2) pf = *reinterpret_cast<const uint32_t *>(base2 + line);
                 }
             }
-            bool busy = false;
+            // The loop is bound by instruction issue (16 waves share 4 SIMDs: every instruction of the round costs
+            // the round ~8 cycles; the LDS pipe would allow ~430 cycles per round, scripts/lds_cas_chain.hip), so it
+            // is kept lean: a lane's state is (e0, q, i) with i == 0 meaning "holds no key"; nothing else lives
+            // across rounds, the diagnostic switches are compiled out of the production instance.
             uint64_t e0 = 0;
-            uint32_t i = 1, q = 0;
-            while (true) {
-                // ---- hand the next keys of the stream to the lanes that have none
+            uint32_t i = 0, q = 0;
+            unsigned long long d_rounds = 0, d_t0 = 0;
+            if (DIAG && (dbg & 16)) d_t0 = __builtin_amdgcn_s_memtime();
+            for (;;) {
+                // ---- hand the next keys of the stream to the lanes that hold none
                 if (taken < total) {
-                    const unsigned long long nm = __ballot(!busy);
+                    const unsigned long long nm = __ballot(i == 0u);
                     if (nm) {
                         const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-                        const uint32_t pp = off + pre;            // position relative to the current batch: 0..126
-                        const int addr = (int)((pp & 63u) << 2);
-                        // every lane takes part: ds_bpermute returns 0 for a source lane that is switched off
-                        uint32_t klo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)cur);
-                        uint32_t khi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(cur >> 32));
-                        const uint32_t cnt = (uint32_t)__builtin_popcountll(nm);
-                        if (off + cnt > 64u) {                    // wave-uniform: some lanes reach into the next batch
-                            const uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)nxt);
-                            const uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(nxt >> 32));
-                            klo = (pp >= 64u) ? nlo : klo;
-                            khi = (pp >= 64u) ? nhi : khi;
+                        const uint32_t pp = off + pre;   // relative to batch cb: 0..126
+                        // consecutive stream positions = consecutive words of the ring: no bank conflicts
+                        const uint64_t kf = ring[(((cb + (pp >> 6)) & 3u) << 6) + (pp & 63u)];
+                        if (i == 0u && taken + pre < total) {
+                            i = 1u;
+                            q = ((uint32_t)kf + 1u) & smask;                    // q_1 = q_0 + 1
+                            e0 = ((kf >> sh_lg) << sh_r) & k0mask;              // split_key for WK = 1
                         }
-                        if (!busy && taken + pre < total) {
-                            const uint64_t key = (uint64_t)klo | ((uint64_t)khi << 32);
-                            busy = true;
-                            i = 1;
-                            q = ((uint32_t)key + 1u) & smask;                     // q_1 = q_0 + 1
-                            e0 = ((key >> p.lg) << p.R) & k0mask;                 // split_key for WK = 1
-                        }
-                        const uint32_t got = min(cnt, total - taken);
-                        taken += got;
-                        off += got;
-                        if (off >= 64u) {
+                        const uint32_t got = min((uint32_t)__builtin_popcountll(nm), total - taken);
+                        taken = __builtin_amdgcn_readfirstlane(taken + got);
+                        off = __builtin_amdgcn_readfirstlane(off + got);
+                        if (off >= 64u) {   // batch cb is used up: its quarter of the ring takes batch cb + 4
                             off -= 64u;
-                            ++cb;
-                            cur = nxt;
-                            nxt = pick_batch(B, cb + 1u);
+                            cb = __builtin_amdgcn_readfirstlane(cb + 1u);
+                            ring[(((cb + 3u) & 3u) << 6) + lane] = pick_batch(B, cb + 3u);
                         }
                     }
                 }
-                if (__ballot(busy) == 0ULL) break;   // stream dry and every key placed
+                if (__ballot(i != 0u) == 0ULL) break;   // stream dry and every key placed
+                if (DIAG) ++d_rounds;
                 // ---- one probe for every lane that holds a key
-                if (busy) {
+                if (i != 0u) {
                     const uint64_t key0 = e0 | i;
                     const unsigned long long old =
                         atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
@@ -809,10 +820,15 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                         atomicAdd(&p.stats[ST_FAIL], 1ULL);
                         placed = true;
                     }
+                    if (DIAG && (dbg & 8)) placed = true;   // ablation: every key 'placed' by its first probe
                     ++i;
                     q = (q + i) & smask;
-                    busy = !placed;
+                    if (placed) i = 0u;
                 }
+            }
+            if (DIAG && (dbg & 16) && lane == 0) {
+                atomicAdd(&p.stats[ST_DBG0], d_rounds);
+                atomicAdd(&p.stats[ST_DBG1], (unsigned long long)(__builtin_amdgcn_s_memtime() - d_t0));
             }
         }
         lds_barrier();

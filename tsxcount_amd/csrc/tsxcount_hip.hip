@@ -690,7 +690,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
@@ -779,8 +780,12 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
         if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
         if (p.wk == 1 && p.W == 1 && build_v == 2) {
-            hipLaunchKernelGGL(build_segments_stream_kernel, dim3(gb), dim3(1024), seg_bytes, st, pp, lists, lists_start,
-                               lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
+            if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
+                hipLaunchKernelGGL((build_segments_stream_kernel<true>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
+            else
+                hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh);
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
                                lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
@@ -1303,6 +1308,18 @@ extern "C" int tsx_hip_kmer_starts_host(tsx_hip_map *m, uint8_t *bits_out, size_
 
 extern "C" int tsx_hip_get_counts_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t *counts_out) {
     return lookup_host(m, kmers, n, counts_out, nullptr);
+}
+
+// Diagnostic builds only (TSX_HIP_DEBUG bit 4): the ST_DBG* counters.  Not part of include/tsxcount_hip.h.
+extern "C" int tsx_hip_debug_counters(tsx_hip_map *m, uint64_t *out8) {
+    if (!m || !out8) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    unsigned long long st[ST_N];
+    int rc = read_stats(m, st);
+    if (rc != TSX_HIP_OK) return rc;
+    for (int i = 0; i < 7; ++i) out8[i] = st[ST_DBG0 + i];
+    out8[7] = 0;
+    return TSX_HIP_OK;
 }
 
 extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
