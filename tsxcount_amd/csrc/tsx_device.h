@@ -79,27 +79,31 @@ struct TableParams {
 };
 
 // Out of line on purpose (rare path; keeps the callers' register budgets): pk points at the kernel's own
-// TableParams argument (the kernel-argument segment).
+// TableParams argument (the kernel-argument segment).  The record travels BY VALUE (in registers): a pointer
+// argument would force the caller's copy of the record into scratch memory, on the fast path too.
+template <int RW> struct RecVal { uint64_t w[RW]; };
 template <int RW>
-__device__ __attribute__((noinline)) void defer_append(const TableParams *pk, const uint64_t *r, uint64_t d) {
+__device__ __attribute__((noinline)) void defer_append_v(const TableParams *pk, RecVal<RW> r, uint64_t d) {
     const unsigned long long at = atomicAdd(pk->defer.n, 1ULL);
     if (at < pk->defer.cap) {
 #pragma unroll
-        for (int t = 0; t < RW; ++t) pk->defer.rec[at * RW + t] = r[t];
+        for (int t = 0; t < RW; ++t) pk->defer.rec[at * RW + t] = r.w[t];
         pk->defer.cnt[at] = d;
     } else {
         atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
     }
 }
-// One-word records by value (a pointer argument would force the caller's key into scratch memory).
-__device__ __attribute__((noinline)) void defer_append1(const TableParams *pk, uint64_t key, uint64_t d) {
-    const unsigned long long at = atomicAdd(pk->defer.n, 1ULL);
-    if (at < pk->defer.cap) {
-        pk->defer.rec[at] = key;
-        pk->defer.cnt[at] = d;
-    } else {
-        atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
-    }
+template <int RW>
+__device__ __forceinline__ void defer_append(const TableParams *pk, const uint64_t *r, uint64_t d) {
+    RecVal<RW> v;
+#pragma unroll
+    for (int t = 0; t < RW; ++t) v.w[t] = r[t];
+    defer_append_v<RW>(pk, v, d);
+}
+__device__ __forceinline__ void defer_append1(const TableParams *pk, uint64_t key, uint64_t d) {
+    RecVal<1> v;
+    v.w[0] = key;
+    defer_append_v<1>(pk, v, d);
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
