@@ -239,6 +239,7 @@ int tsx_hip_hash_rows(const tsx_hip_map *m, uint64_t *rows_out /* 2k x key_limbs
  *   -- all-to-all of the owner groups (RCCL), all-gather of the hot lists --
  *   shard_build_device  builds the received keys into this GPU's slot range (radix
  *                       partition + LDS segment build); *dev_key_sum (optional) += their sum.
+ *                       shard_build_pieces_device: the same for several runs of keys at once.
  *   add_hashed_device   adds (hashed key, count) pairs, skipping other owners' keys.
  * tsxcount_amd/distributed.py: ShardedCounter.
  */
@@ -253,6 +254,11 @@ int tsx_hip_shard_scan_device(tsx_hip_map *m, const void *dev_text, size_t n, vo
                               void *dev_hot_counts, size_t hot_cap, void *dev_hot_n, void *stream);
 int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *dev_key_sum,
                                void *stream);
+/* The same for keys that arrived in several runs (own keys and one run per exchange window): run i is
+ * piece_cnt[i] keys at dev_keys + piece_off[i] (host arrays, in keys).  ONE partition + build for all of
+ * them: a build costs a full pass over this GPU's slot range however few keys it brings. */
+int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev_keys, const uint64_t *piece_off,
+                                      const uint64_t *piece_cnt, size_t npieces, void *dev_key_sum, void *stream);
 int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
                               void *stream);
 

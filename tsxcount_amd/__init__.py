@@ -78,6 +78,7 @@ def lib():
     L.tsx_hip_shard_scan_device.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, sz, vp, vp]
     L.tsx_hip_shard_scan_window_device.argtypes = [vp, vp, sz, sz, sz, vp, sz, vp, sz, vp, vp, vp, sz, vp, vp, vp]
     L.tsx_hip_shard_build_device.argtypes = [vp, vp, sz, vp, vp]
+    L.tsx_hip_shard_build_pieces_device.argtypes = [vp, vp, u64p, u64p, sz, vp, vp]
     L.tsx_hip_add_hashed_device.argtypes = [vp, vp, vp, sz, vp]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None

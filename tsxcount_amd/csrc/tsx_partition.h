@@ -330,13 +330,51 @@ __global__ __launch_bounds__(PART_NT) void deferred_insert_kernel(TableParams p,
                                                                   uint64_t cap) {
     constexpr int RW = RecWords<WK>::value;
     const uint64_t n = min(n_ptr ? (uint64_t)*n_ptr : n_fixed, cap);
-    for (uint64_t i = (uint64_t)blockIdx.x * PART_NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PART_NT) {
-        uint64_t h[WK];
+    if constexpr (WK == 1) {
+        // The list is mostly the same few hot k-mers over and over (every scan wave drains its homopolymer
+        // cache, every level-2 workgroup its spill cache): a workgroup first sums equal keys of its share in
+        // an LDS table, so that a hot key costs one same-address global atomic per WORKGROUP, not per entry.
+        constexpr uint32_t DN = 1024;
+        __shared__ uint64_t s_k[DN];
+        __shared__ unsigned long long s_c[DN];
+        const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+        const uint64_t lo = min(n, (uint64_t)blockIdx.x * per), hi = min(n, lo + per);
+        for (uint64_t base = lo; base < hi; base += DN / 2) {   // table at most half full
+            for (uint32_t t = threadIdx.x; t < DN; t += PART_NT) { s_k[t] = 0; s_c[t] = 0; }
+            __syncthreads();
+            const uint64_t end = min(hi, base + DN / 2);
+            for (uint64_t i = base + threadIdx.x; i < end; i += PART_NT) {
+                const uint64_t key = rec[i], d = cnt ? cnt[i] : 1ULL;
+                const uint64_t h1[1] = {key};
+                if (d == 0 || (p.lg != p.l && owner_shard<1>(p, h1) != p.shard)) continue;
+                const uint64_t kk = key ^ OVF_SALT;
+                uint32_t slot = (uint32_t)(mix64(key) >> 40) & (DN - 1);
+                bool done = false;
+                for (int pr = 0; pr < 16 && kk != 0 && !done; ++pr) {
+                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_k[slot]), 0ULL,
+                                                             (unsigned long long)kk);
+                    if (old == 0ULL || old == kk) { atomicAdd(&s_c[slot], (unsigned long long)d); done = true; }
+                    slot = (slot + 1) & (DN - 1);
+                }
+                if (!done) insert_key<1>(p, h1, d);
+            }
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < DN; t += PART_NT)
+                if (s_c[t]) {
+                    const uint64_t h1[1] = {s_k[t] ^ OVF_SALT};
+                    insert_key<1>(p, h1, s_c[t]);
+                }
+            __syncthreads();
+        }
+    } else {
+        for (uint64_t i = (uint64_t)blockIdx.x * PART_NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PART_NT) {
+            uint64_t h[WK];
 #pragma unroll
-        for (int t = 0; t < WK; ++t) h[t] = rec[i * RW + t];
-        const uint64_t d = cnt ? cnt[i] : 1ULL;
-        if (d == 0 || (p.lg != p.l && owner_shard<WK>(p, h) != p.shard)) continue;
-        insert_key<WK>(p, h, d);
+            for (int t = 0; t < WK; ++t) h[t] = rec[i * RW + t];
+            const uint64_t d = cnt ? cnt[i] : 1ULL;
+            if (d == 0 || (p.lg != p.l && owner_shard<WK>(p, h) != p.shard)) continue;
+            insert_key<WK>(p, h, d);
+        }
     }
 }
 
@@ -441,12 +479,12 @@ __global__ __launch_bounds__(PART_NT) void split_owner_kernel(const uint64_t *sr
     }
 }
 
-// Level-1 histogram of an arbitrary key array cut into G equal regions (the keys a
-// shard received): hist[b * G + g], the layout offsets_kernel scans.
-__global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uint64_t n, uint64_t region_len,
-                                                       uint32_t G, uint32_t nb, uint32_t shift, uint32_t *hist,
-                                                       unsigned long long *region_start, unsigned long long *region_cnt,
-                                                       unsigned long long *key_sum) {
+// Level-1 histogram of received keys: G regions given by (region_start, region_cnt) -- cuts of the pieces
+// a shard received, own keys and one run per exchange window -- into hist[b * G + g], the layout
+// offsets_kernel scans.
+__global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uint32_t G, uint32_t nb, uint32_t shift,
+                                                       uint32_t *hist, const unsigned long long *region_start,
+                                                       const unsigned long long *region_cnt, unsigned long long *key_sum) {
     __shared__ uint32_t s_h[512];
     const uint32_t tid = threadIdx.x;
     unsigned long long sum = 0;   // integrity: sum of every key received (see split_owner_kernel)
@@ -454,7 +492,7 @@ __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uin
         lds_barrier();
         for (uint32_t b = tid; b < nb; b += PART_NT) s_h[b] = 0;
         lds_barrier();
-        const uint64_t lo = min(n, (uint64_t)g * region_len), hi = min(n, lo + region_len);
+        const uint64_t lo = region_start[g], hi = lo + region_cnt[g];
         // four independent loads per thread and round: the kernel is a stream, not a latency chain
         uint64_t i = lo + tid;
         for (; i + 3 * PART_NT < hi; i += 4 * PART_NT) {
@@ -472,7 +510,6 @@ __global__ __launch_bounds__(PART_NT) void hist_kernel(const uint64_t *keys, uin
         }
         lds_barrier();
         for (uint32_t b = tid; b < nb; b += PART_NT) hist[(size_t)b * G + g] = s_h[b];
-        if (tid == 0) { region_start[g] = lo; region_cnt[g] = hi - lo; }
     }
     if (key_sum) {
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);

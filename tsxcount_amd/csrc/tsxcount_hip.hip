@@ -87,6 +87,7 @@ struct tsx_hip_map {
     std::vector<hipEvent_t> ev;      // seven per piece: before pass 1, before pass 3, after pass 3, start of the
                                      // partition phase (later than the scan's end only in a sharded run: the
                                      // exchange lies between), after level 1, level 2, build
+    std::vector<unsigned long long> h_regions;   // host copy of the region table of a sharded build (starts, then sizes)
     std::deque<long> ev_open;        // tuples of shard scans whose partition phase has not run yet (oldest first)
     size_t ev_used = 0;
 };
@@ -990,43 +991,70 @@ extern "C" int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, si
     return TSX_HIP_OK;
 }
 
-extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *dev_key_sum,
-                                          void *stream) {
-    if (!m || (!dev_keys && n_keys) || ((uintptr_t)dev_keys & 7)) return TSX_HIP_EINVAL;
+extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev_keys, const uint64_t *piece_off,
+                                                 const uint64_t *piece_cnt, size_t npieces, void *dev_key_sum,
+                                                 void *stream) {
+    if (!m || !dev_keys || ((uintptr_t)dev_keys & 7) || (npieces && (!piece_off || !piece_cnt))) return TSX_HIP_EINVAL;
     unsigned long long *key_sum = (unsigned long long *)dev_key_sum;
+    uint64_t n_keys = 0;
+    for (size_t i = 0; i < npieces; ++i) n_keys += piece_cnt[i];
     if (n_keys == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
+    const uint64_t *keys = (const uint64_t *)dev_keys;
     if (!can_partition(m)) {  // tiny tables: plain atomic inserts of the hashed keys
         int rcz = ensure_zeroed(m, st);
         if (rcz != TSX_HIP_OK) return rcz;
-        const int grid = grid_for(m, n_keys, 8);
-        hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
-                           (const uint64_t *)nullptr, (uint64_t)n_keys, key_sum);
-        HIP_TRY(hipGetLastError());
+        for (size_t i = 0; i < npieces; ++i) {
+            if (!piece_cnt[i]) continue;
+            hipLaunchKernelGGL(add_hashed_kernel, dim3(grid_for(m, piece_cnt[i], 8)), dim3(PART_NT), 0, st, m->p,
+                               keys + piece_off[i], (const uint64_t *)nullptr, (uint64_t)piece_cnt[i], key_sum);
+            HIP_TRY(hipGetLastError());
+        }
         if (!m->ev_open.empty()) m->ev_open.pop_front();
         return TSX_HIP_OK;
     }
-    const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>((n_keys + 4095) / 4096, (uint64_t)m->cus * 3));
+    // regions of the level-1 partition: every piece cut into runs of about n_keys / (3 per CU) keys
+    const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>((n_keys + 4095) / 4096, (uint64_t)m->cus * 3));
+    const uint64_t region_len = (n_keys + want - 1) / want;
+    m->h_regions.clear();
+    std::vector<unsigned long long> cnts;
+    for (size_t i = 0; i < npieces; ++i)
+        for (uint64_t o = 0; o < piece_cnt[i]; o += region_len) {
+            m->h_regions.push_back(piece_off[i] + o);
+            cnts.push_back(std::min<uint64_t>(region_len, piece_cnt[i] - o));
+        }
+    const int g = (int)m->h_regions.size();
+    m->h_regions.insert(m->h_regions.end(), cnts.begin(), cnts.end());
     PartPlan pl;
     int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl);
     if (rc != TSX_HIP_OK) return rc;
     rc = ensure_deferred(m, n_keys + 65536, st);
     if (rc != TSX_HIP_OK) return rc;
     HIP_TRY(hipMemsetAsync(m->d_def_n, 0, 8, st));
+    // region table: starts into c_rstart, sizes into c_log (plan_partition laid them out back to back: [c_log | c_rstart])
+    HIP_TRY(hipMemcpyAsync(pl.c_rstart, m->h_regions.data(), (size_t)g * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(pl.c_log, m->h_regions.data() + g, (size_t)g * 8, hipMemcpyHostToDevice, st));
     hipEvent_t *ev = nullptr;
     if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + 7 <= m->ev_used) {
         ev = &m->ev[(size_t)m->ev_open.front()];
         HIP_TRY(hipEventRecord(ev[3], st));   // the histogram of the received keys counts as level 1
     }
     if (!m->ev_open.empty()) m->ev_open.pop_front();
-    const uint64_t region_len = (n_keys + g - 1) / g;
-    hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, (const uint64_t *)dev_keys, (uint64_t)n_keys, region_len,
-                       (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1), pl.d_hist, pl.c_rstart, pl.c_log, key_sum);
+    hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, keys, (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1),
+                       pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
     HIP_TRY(hipGetLastError());
-    rc = run_partition_build(m, pl, (const uint64_t *)dev_keys, pl.c_rstart, 0, st, ev);
+    rc = run_partition_build(m, pl, keys, pl.c_rstart, 0, st, ev);
     if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[6], st));
     return rc;
+}
+
+extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, void *dev_key_sum,
+                                          void *stream) {
+    if (!m || (!dev_keys && n_keys)) return TSX_HIP_EINVAL;
+    if (n_keys == 0) return TSX_HIP_OK;
+    const uint64_t off = 0, cnt = n_keys;
+    return tsx_hip_shard_build_pieces_device(m, dev_keys, &off, &cnt, 1, dev_key_sum, stream);
 }
 
 extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,

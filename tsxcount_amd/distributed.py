@@ -199,23 +199,25 @@ class ShardedCounter:
 
     Rank r holds home slots [r << l, (r+1) << l) of a table with 2^(l + log2 world)
     slots (TSXHashMapHIP(..., shard_bits=log2 world, shard_index=r)).  step() counts one
-    device text of this rank's reads:
+    device text of this rank's reads, cut into W windows:
 
-        compute stream   scan(0) scan(1) build(0) scan(2) build(1) ... build(W-1)
-        exchange stream        sizes(0) a2a(0)  sizes(1) a2a(1) ...
+        compute stream   scan(0) scan(1) scan(2) ... scan(W-1)            build
+        exchange stream        sizes(0) a2a(0)  sizes(1) a2a(1) ... a2a(W-1)
 
     scan(i)   tsx_hip_shard_scan_window_device: window i of the text -> keys grouped by owner
               (own keys straight into the receive buffer), per-owner counts, hot (key, count) list
     sizes(i)  ONE small all-to-all carries, per pair: keys to come, this rank's status, the
               length of its hot list.  Its result is the only thing the host waits for, and it
               waits while scan(i+1) is already queued on the GPU
-    a2a(i)    ONE all_to_all_single with split sizes, from the send buffer into the receive buffer
-              behind the own keys; hot lists by all-gather (owners pick theirs)
-    build(i)  tsx_hip_shard_build_device + tsx_hip_add_hashed_device
+    a2a(i)    ONE all_to_all_single with split sizes, from the send buffer into window i's part of
+              the receive buffer, behind the own keys; hot lists by all-gather (owners pick theirs)
+    build     ONE tsx_hip_shard_build_pieces_device over all windows' keys (a build costs a pass
+              over the whole slot range, however few keys it brings), then the hot lists
 
-    Two send / receive / hot buffers alternate.  Integrity: every scan adds the sum of the keys it
-    wrote, every build the sum of the keys it read; the two totals must agree over all ranks
-    (one all-reduce per step).  After step() rank r answers getKmerCount for the k-mers it owns.
+    The exchange of window i overlaps the scan of window i+1; two send and hot buffers alternate.
+    Integrity: every scan adds the sum of the keys it wrote, the build the sum of the keys it
+    read; the two totals must agree over all ranks (one all-reduce per step).  After step() rank r
+    answers getKmerCount for the k-mers it owns.
     """
 
     HOT_CAP = 1 << 18
@@ -237,15 +239,17 @@ class ShardedCounter:
         self.send_cap = cap.value
         i64 = dict(dtype=torch.int64, device=self.dev)
         self.send = [torch.empty((self.send_cap,), **i64) for _ in range(2)]
-        # receive buffer: own keys in front (any number up to the window's total), the peers' behind
-        self.recv = [torch.empty((2 * self.send_cap,), **i64) for _ in range(2)]
+        # receive buffer: one part per window -- own keys in front (any number up to the window's total),
+        # the peers' behind them
+        self.part = 2 * self.send_cap
+        self.recv = torch.empty((self.windows * self.part,), **i64)
         self.counts = [torch.zeros((self.world,), **i64) for _ in range(2)]
         self.hot_k = [torch.zeros((self.HOT_CAP,), **i64) for _ in range(2)]
         self.hot_c = [torch.zeros((self.HOT_CAP,), **i64) for _ in range(2)]
         self.hot_n = [torch.zeros((1,), **i64) for _ in range(2)]
-        self.hot_all_k = [torch.zeros((0,), **i64) for _ in range(2)]
-        self.hot_all_c = [torch.zeros((0,), **i64) for _ in range(2)]
-        self.sums = torch.zeros((2,), **i64)      # [0] += keys written by the scans, [1] += keys read by the builds
+        self.hot_all_k = [torch.zeros((0,), **i64) for _ in range(self.windows)]
+        self.hot_all_c = [torch.zeros((0,), **i64) for _ in range(self.windows)]
+        self.sums = torch.zeros((2,), **i64)      # [0] += keys written by the scans, [1] += keys read by the build
         self.cs = torch.cuda.Stream(self.dev)     # every kernel of a step
         self.xs = torch.cuda.Stream(self.dev)     # the collectives
         self.ev_scan = [torch.cuda.Event() for _ in range(2)]
@@ -256,9 +260,10 @@ class ShardedCounter:
         m, L, vp, b = self.m, self.m._lib, ctypes.c_void_p, i & 1
         off = i * self.win_bytes
         ln = max(0, min(self.win_bytes, nbytes - off))
+        own_ptr = self.recv.data_ptr() + i * self.part * 8
         rc = L.tsx_hip_shard_scan_window_device(
             m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln, vp(self.send[b].data_ptr()), self.send_cap,
-            vp(self.recv[b].data_ptr()), self.recv[b].numel(), vp(self.counts[b].data_ptr()),
+            vp(own_ptr), self.part, vp(self.counts[b].data_ptr()),
             vp(self.hot_k[b].data_ptr()), vp(self.hot_c[b].data_ptr()), self.HOT_CAP, vp(self.hot_n[b].data_ptr()),
             vp(self.sums.data_ptr()), vp(self.cs.cuda_stream))
         self.ev_scan[b].record(self.cs)
@@ -274,14 +279,16 @@ class ShardedCounter:
         self.cs.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.cs):
             self.sums.zero_()
-        n_recv_total = 0
         failure = None
+        piece_off, piece_cnt, hot_g = [], [], []
         rc_scan = self._scan(0, text_ptr, nbytes)
         for i in range(nwin):
             b = i & 1
             rc_this = rc_scan
-            if i + 1 < nwin and failure is None:
-                rc_scan = self._scan(i + 1, text_ptr, nbytes)   # queued before the host waits for window i
+            if i + 1 < nwin:
+                if i >= 1:
+                    self.cs.wait_event(self.ev_exch[(i + 1) & 1])   # exchange i-1 has finished with the buffers scan i+1 reuses
+                rc_scan = self._scan(i + 1, text_ptr, nbytes)       # queued before the host waits for window i
             with torch.cuda.stream(self.xs):
                 self.xs.wait_event(self.ev_scan[b])
                 # sizes(i): row p = [keys for p, my status, my hot keys]
@@ -303,41 +310,40 @@ class ShardedCounter:
                 ss = [0 if p == rank else mine[p] for p in range(world)]
                 rs = [0 if p == rank else int(mo[p, 0]) for p in range(world)]
                 n_recv = own + sum(rs)
-                if n_recv > self.recv[b].numel():   # skewed ownership: grow, keeping the own keys already there
-                    bigger = torch.empty((n_recv + n_recv // 4,), dtype=torch.int64, device=self.dev)
-                    bigger[:own] = self.recv[b][:own]
-                    self.xs.synchronize()
-                    self.recv[b] = bigger
-                if world > 1:
-                    comm.all_to_all(self.recv[b][own:n_recv], self.send[b][:sum(ss)], rs, ss)
+                if n_recv > self.part:
+                    failure = (i, [-7])   # TSX_HIP_ERANGE: ownership far more skewed than the receive buffer allows
+                part = self.recv[i * self.part:(i + 1) * self.part]
+                if world > 1 and failure is None:
+                    comm.all_to_all(part[own:n_recv], self.send[b][:sum(ss)], rs, ss)
                 # hot lists: padded to the longest, gathered everywhere, owners pick theirs
-                nh = max(int(x) for x in mo[:, 2].tolist())
-                nh = min(max(nh, 0), self.HOT_CAP)
+                nh = min(max(max(int(x) for x in mo[:, 2].tolist()), 0), self.HOT_CAP)
                 g = 0
                 if nh:
                     g = 1 << (nh - 1).bit_length()
                     self.hot_c[b][my_hot:g].zero_()   # entries past this rank's own list carry count 0 = ignored
-                    if self.hot_all_k[b].numel() < g * world:
-                        self.hot_all_k[b] = torch.empty((g * world,), dtype=torch.int64, device=self.dev)
-                        self.hot_all_c[b] = torch.empty((g * world,), dtype=torch.int64, device=self.dev)
-                    comm.all_gather(self.hot_all_k[b][:g * world], self.hot_k[b][:g])
-                    comm.all_gather(self.hot_all_c[b][:g * world], self.hot_c[b][:g])
+                    if self.hot_all_k[i].numel() < g * world:
+                        self.hot_all_k[i] = torch.empty((g * world,), dtype=torch.int64, device=self.dev)
+                        self.hot_all_c[i] = torch.empty((g * world,), dtype=torch.int64, device=self.dev)
+                    comm.all_gather(self.hot_all_k[i][:g * world], self.hot_k[b][:g])
+                    comm.all_gather(self.hot_all_c[i][:g * world], self.hot_c[b][:g])
                 self.ev_exch[b].record(self.xs)
-            self.cs.wait_event(self.ev_exch[b])
-            rc = L.tsx_hip_shard_build_device(m.handle, vp(self.recv[b].data_ptr()), n_recv, vp(self.sums[1:].data_ptr()),
-                                              vp(self.cs.cuda_stream))
-            if rc == OK and g:
-                rc = L.tsx_hip_add_hashed_device(m.handle, vp(self.hot_all_k[b].data_ptr()),
-                                                 vp(self.hot_all_c[b].data_ptr()), g * world, vp(self.cs.cuda_stream))
+            piece_off.append(i * self.part)
+            piece_cnt.append(n_recv if failure is None else 0)
+            hot_g.append(g)
+        # ---- ONE partition + build over everything this rank owns, then the hot (key, count) lists
+        n_recv_total = sum(piece_cnt)
+        self.cs.wait_stream(self.xs)
+        if failure is None:
+            po = (ctypes.c_uint64 * len(piece_off))(*piece_off)
+            pc = (ctypes.c_uint64 * len(piece_cnt))(*piece_cnt)
+            rc = L.tsx_hip_shard_build_pieces_device(m.handle, vp(self.recv.data_ptr()), po, pc, len(piece_off),
+                                                     vp(self.sums[1:].data_ptr()), vp(self.cs.cuda_stream))
+            for i, g in enumerate(hot_g):
+                if rc == OK and g:
+                    rc = L.tsx_hip_add_hashed_device(m.handle, vp(self.hot_all_k[i].data_ptr()),
+                                                     vp(self.hot_all_c[i].data_ptr()), g * world, vp(self.cs.cuda_stream))
             if rc != OK:
-                # the next sizes exchange carries it to the peers; in the last window the final agreement does
-                rc_scan = rc if i + 1 < nwin else rc_scan
-                failure_local = rc
-            else:
-                failure_local = OK
-            n_recv_total += n_recv
-            if failure_local != OK and i + 1 >= nwin:
-                failure = (i, [failure_local])
+                failure = (nwin, [rc])
         self.cs.synchronize()
         self.xs.synchronize()
         # integrity of the exchange + agreement on failures: one small all-reduce per step
