@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/prof_r1 (scripts/profile_round1.sh) into the committed summaries
-under profiles/: kernel stats per insert path, PMC counters per kernel, and
-round1_pmc.json (HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes:
-FETCH_SIZE tallies 128-B read requests at 64 B on gfx950 -> x2; both are in KiB)."""
+"""Turns gpurun_out/prof_r<N> (scripts/profile_round<N>.sh) into the committed summaries
+under profiles/: kernel stats, PMC counters per kernel, and round<N>_pmc.json (HBM bytes per
+launch, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE tallies 128-B read requests at
+64 B on gfx950 -> x2; both are in KiB).  Usage: summarize_profiles.py [round]  (default 2)."""
 import collections
 import csv
 import glob
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r1")
+ROUND = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r%d" % ROUND)
+TRACES = ("partitioned", "atomic") if ROUND == 1 else ("k31", "k63")
+PMCDIR = "pmc_partitioned_*" if ROUND == 1 else "pmc_k31_*"
+BUILD = "tsx::build_segments_kernel" if ROUND == 1 else "tsx::build_segments_stream_kernel<false>"
 DST = os.path.join(ROOT, "profiles")
 TEXT_BYTES = 2081065118
 
-for path in ("partitioned", "atomic"):
+for path in TRACES:
     f = sorted(glob.glob(os.path.join(SRC, "trace_" + path, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if f:
-        shutil.copy(f[-1], os.path.join(DST, "round1_kernel_stats_%s.csv" % path))
+        shutil.copy(f[-1], os.path.join(DST, "round%d_kernel_stats_%s.csv" % (ROUND, path)))
 
 agg = collections.defaultdict(dict)
 per_dispatch = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> counter -> {dispatch id: value}
@@ -32,19 +37,19 @@ def newest(pattern):
     return [best[d] for d in sorted(best)]
 
 
-for f in newest(os.path.join(SRC, "pmc_partitioned_*", "*", "*_counter_collection.csv")):
+for f in newest(os.path.join(SRC, PMCDIR, "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] = agg[k].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         d = per_dispatch[k][r["Counter_Name"]]
         d[int(r["Dispatch_Id"])] = d.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
-with open(os.path.join(DST, "round1_pmc_counters_partitioned.csv"), "w") as out:
+with open(os.path.join(DST, "round%d_pmc_counters_%s.csv" % (ROUND, "partitioned" if ROUND == 1 else "k31")), "w") as out:
     out.write("kernel,counter,sum_over_dispatches_of_one_bench_run(steps=1,warmup=0)\n")
     for k in sorted(agg):
         for c in sorted(agg[k]):
             out.write("%s,%s,%.3f\n" % (k, c, agg[k][c]))
 
-summary_path = os.path.join(DST, "round1_pmc.json")
+summary_path = os.path.join(DST, "round%d_pmc.json" % ROUND)
 summary = json.load(open(summary_path)) if os.path.exists(summary_path) else {}
 if "kernel" in summary:  # first layout of this file: the atomic path only
     summary = {"atomic": summary}
@@ -73,9 +78,9 @@ def nth_dispatch_bytes(kernel, nth):
         return None
     return rd[nth] * 2048 + wr[nth] * 1024
 part["stages"] = {"scan": nth_dispatch_bytes("tsx::scan_log_kernel", 0),
-                  "level1": nth_dispatch_bytes("tsx::partition_ring_kernel", 0),
-                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel", 1),
-                  "build": nth_dispatch_bytes("tsx::build_segments_kernel", 0)}
+                  "level1": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0),
+                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 1),
+                  "build": nth_dispatch_bytes(BUILD, 0)}
 part["hbm_bytes_whole_path_per_step"] = tot_r + tot_w
 lc = agg.get("tsx::line_count_kernel", {})
 if "FETCH_SIZE" in lc:

@@ -240,6 +240,11 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
             for (int t = 0; t < RW; ++t) cur[q][t] = 0;
         }
     }
+    // The first batch must have ARRIVED before the loop: the compiler then knows that `cur` is complete at the
+    // loop header on both edges and waits for the next batch's loads where they are consumed (the copies at the
+    // end of the batch) -- not right behind their issue, which is what it did without this wait: vmcnt(0) in
+    // front of the first use of `cur`, i.e. one full HBM latency per batch and no prefetch at all.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     for (; base < n; base += stride) {
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
