@@ -1,9 +1,8 @@
 #!/bin/bash
-# build-kernel variants: stage times from bench.py (no check)
 mkdir -p gpurun_out
 run() {
   tag=$1; shift
-  env "$@" timeout -k 10 200 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-cross-check --check-reads 200 > gpurun_out/mx_$tag.json 2> gpurun_out/mx_$tag.err
+  env "$@" timeout -k 10 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-cross-check --check-reads 200 > gpurun_out/mx_$tag.json 2> gpurun_out/mx_$tag.err
   python - <<PY
 import json
 try:
@@ -12,6 +11,7 @@ try:
 except Exception as e: print("$tag ERR", e)
 PY
 }
-run stream X=1
-run stream_first TSX_HIP_DEBUG=8
-run fifo TSX_HIP_BUILD_V=1
+run pf1 TSX_HIP_BUILD_PREFETCH=1
+run pf0 TSX_HIP_BUILD_PREFETCH=0
+run pf1b TSX_HIP_BUILD_PREFETCH=1
+run pf0b TSX_HIP_BUILD_PREFETCH=0

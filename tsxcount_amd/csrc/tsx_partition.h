@@ -724,7 +724,7 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                                                                      const unsigned long long *list_start,
                                                                      const unsigned long long *list_cnt,
                                                                      uint64_t list_cap, uint32_t pieces, uint32_t nseg,
-                                                                     int dbg_arg, int fresh) {
+                                                                     int dbg_arg, int fresh, int prefetch) {
     const int dbg = DIAG ? dbg_arg : 0;
     extern __shared__ uint64_t s_seg[];  // 2^S slots, then four batches of 64 keys per wave
     const uint32_t nslots = 1u << p.S;
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                 // the next segment's lists start towards L2 now and stay in flight while this segment is
                 // inserted and written out: lane L of the lanes that share a list touches line L of it
                 const uint32_t nseg2 = seg + gridDim.x;
-                if (nseg2 < nseg) {
+                if (prefetch && nseg2 < nseg) {
                     const uint64_t *base2;
                     const uint32_t mine2 = my_list(nseg2, base2);
                     const uint32_t line = (wi * 64u + lane) * 16u;             // first key of this lane's line

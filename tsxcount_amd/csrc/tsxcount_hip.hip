@@ -397,7 +397,10 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l, in
     const size_t lut8 = (size_t)((p.n + 7) / 8) * 256 * p.wk * 8;
     p.g = (lut8 <= (32u << 10)) ? 8 : 4;
     p.groups = (p.n + p.g - 1) / p.g;
-    int ol = overflow_l ? overflow_l : std::max(10, l - 4);
+    // secondary array: one entry per slot whose counter overflowed.  With the automatic (wide) counters that
+    // is a handful of hot k-mers: 2^(l-8) entries; with explicit narrow --s counters many keys carry: 2^(l-4).
+    // (It is cleared with the table whenever something carried: 1 GiB at l = 30 cost 0.23 ms per clear.)
+    int ol = overflow_l ? overflow_l : std::max(10, (s == 0 && C >= 16) ? l - 8 : l - 4);
     if (ol < 4 || ol > 34) return TSX_HIP_EINVAL;
     p.sec_mask = (1ULL << ol) - 1ULL;
     tsx_hip_layout &L = m->lay;
@@ -780,13 +783,17 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         const size_t seg_bytes = ((size_t)8 << p.S) * p.W;
         static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
         if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
+        static int build_pf = -1;   // TSX_HIP_BUILD_PREFETCH=0|1: pull the next segment's lists towards L2 during the insert
+        // off by default: it saves 0.1 ms of 6.3 but the prefetched lines rarely survive in L2 until they are
+        // used -- the key lists are then read from HBM twice (12.6 GB instead of 6.5 GB, profiles/README.md)
+        if (build_pf < 0) { const char *e = getenv("TSX_HIP_BUILD_PREFETCH"); build_pf = e ? atoi(e) : 0; }
         if (p.wk == 1 && p.W == 1 && build_v == 2) {
             if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
                 hipLaunchKernelGGL((build_segments_stream_kernel<true>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_pf);
             else
                 hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh);
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_pf);
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
                                lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
