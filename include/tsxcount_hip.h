@@ -132,6 +132,14 @@ int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n);
 int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream);
 
 /*
+ * Lines per record of the texts handed to the count_fastq / shard_scan entry points: 4 = FASTQ
+ * (FASTQEntry, FastXReader.h:62-95; the default), 2 = FASTA exactly as FASTXreader<FASTAEntry> reads it
+ * (FastXReader.h:97-116: header line, ONE sequence line; sequences wrapped over several lines are not
+ * joined there either).  Empty lines are dropped in both.
+ */
+int tsx_hip_set_record_lines(tsx_hip_map *m, int lines);
+
+/*
  * Measurement hooks (no reference counterpart): with timing enabled every
  * FASTQ piece records HIP events on its launch stream around the line passes,
  * around count_fastq_kernel and around the partition + segment-build kernels.

@@ -45,6 +45,8 @@ def lib():
         L.orc_dump.argtypes = [ctypes.c_void_p, u64p, u64p, ctypes.c_uint64]
         L.orc_count_fastq.restype = ctypes.c_int64
         L.orc_count_fastq.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]
+        L.orc_count_fastx.restype = ctypes.c_int64
+        L.orc_count_fastx.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -102,8 +104,8 @@ class Oracle:
         k = np.ascontiguousarray(kmer, dtype=np.uint64)
         return int(lib().orc_get_count(self._h, _p(k)))
 
-    def count_fastq(self, data):
-        n = lib().orc_count_fastq(self._h, data, len(data))
+    def count_fastq(self, data, lines_per_record=4):
+        n = lib().orc_count_fastx(self._h, data, len(data), lines_per_record)
         if n < 0:
             raise RuntimeError("oracle table exhausted")
         return int(n)

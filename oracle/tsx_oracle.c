@@ -464,14 +464,18 @@ uint64_t orc_dump(const orc_t *o, uint64_t *kmers_out, uint64_t *counts_out, uin
  * lines are dropped, every group of 4 remaining lines is one record whose
  * second line is the sequence.  Returns the number of k-mers added, or -1
  * when the table ran out of room.                                            */
-int64_t orc_count_fastq(orc_t *o, const char *buf, uint64_t n) {
+int64_t orc_count_fastx(orc_t *o, const char *buf, uint64_t n, int lines_per_record);
+int64_t orc_count_fastq(orc_t *o, const char *buf, uint64_t n) { return orc_count_fastx(o, buf, n, 4); }
+/* lines_per_record: 4 = FASTQEntry (FastXReader.h:62-95), 2 = FASTAEntry (FastXReader.h:97-116: lines[0] is the
+ * read id, lines[1] the sequence -- one line, FASTXreader does not join wrapped sequences).                     */
+int64_t orc_count_fastx(orc_t *o, const char *buf, uint64_t n, int lines_per_record) {
     uint64_t line_no = 0, i = 0; int64_t added = 0;
     uint64_t kmer[ORC_LIMBS];
     while (i < n) {
         uint64_t e = i; while (e < n && buf[e] != '\n') ++e;
         uint64_t len = e - i;
         if (len > 0) {
-            if ((line_no & 3) == 1 && len >= (uint64_t)o->k) {
+            if ((line_no % (uint64_t)lines_per_record) == 1 && len >= (uint64_t)o->k) {
                 for (uint64_t p = 0; p + o->k <= len; ++p) {
                     orc_encode(buf + i + p, o->k, kmer);
                     if (!orc_add_kmer(o, kmer)) return -1;

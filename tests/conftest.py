@@ -48,13 +48,13 @@ def golden_counts():
     return ref
 
 
-def python_counts(text, k):
-    """Independent dictionary count of a FASTQ text with the reference's record
-    rules (FastXReader.h:359-372, testExecution.h:15-36)."""
+def python_counts(text, k, lines_per_record=4):
+    """Independent dictionary count of a FASTQ (4 lines per record) or FASTA (2, as FASTXreader<FASTAEntry>
+    reads it) text with the reference's record rules (FastXReader.h:62-116,359-372, testExecution.h:15-36)."""
     from collections import Counter
     lines = [l for l in text.split(b"\n") if len(l) > 0]
     c = Counter()
-    for seq in lines[1::4]:
+    for seq in lines[1::lines_per_record]:
         for i in range(len(seq) - k + 1):
             c[seq[i:i + k]] += 1
     return c

@@ -475,6 +475,42 @@ def test_fuzzed_record_structure_both_paths(T, seed):
     assert_same_as_oracle(T, text, k, 15, 2, path="atomic", overflow_l=15)
 
 
+@pytest.mark.parametrize("k,l,path", [(21, 16, "atomic"), (21, 16, "partitioned"), (31, 20, "partitioned"),
+                                      (63, 18, "partitioned"), (127, 18, "atomic"), (127, 18, "partitioned")])
+def test_fasta_records(T, k, l, path):
+    """tsx_hip_set_record_lines(2): FASTA as FASTXreader<FASTAEntry> reads it (FastXReader.h:97-116) -- header
+    line, one sequence line, empty lines dropped; nearly every byte starts a k-mer (no quality lines), which
+    also sizes the key log differently.  Against the oracle with the same record rule."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(k + l)
+    recs = []
+    for r in range(400):
+        n = int(rng.integers(1, 4 * k + 60))
+        recs.append(b">read%d len=%d\n" % (r, n) + bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=n,
+                                                                 p=[0.24, 0.25, 0.25, 0.25, 0.01])) + b"\n")
+        if r % 11 == 0:
+            recs.append(b"\n")
+    text = b"".join(recs)
+    o = Oracle(k, 20, 4, seed=1)
+    n = o.count_fastq(text, 2)
+    m = T.TSXHashMapHIP(l, 0, k)
+    m.set_record_lines(2)
+    m.set_path(path)
+    m.countFastq(text)
+    st = m.stats()
+    assert st["kmers_added"] == n and st["distinct"] == o.distinct() and st["insert_failures"] == 0
+    kmers, counts = o.dump()
+    assert np.array_equal(m.getKmerCounts(kmers), counts)
+    # the same text read as FASTQ gives something else entirely (every 4th line only)
+    m2 = T.TSXHashMapHIP(l, 0, k)
+    m2.set_path(path)
+    m2.countFastq(text)
+    assert m2.stats()["kmers_added"] == Oracle(k, 20, 4, seed=1).count_fastq(text, 4) != n
+    m.close(); m2.close()
+    with pytest.raises(T.TSXException):
+        T.TSXHashMapHIP(l, 0, k).set_record_lines(3)
+
+
 def test_long_reads_span_many_tiles(T):
     # one 50 kb read (the bundled fixture has 20 kb reads) + long header and quality lines
     rng = np.random.default_rng(3)

@@ -103,3 +103,27 @@ def test_oracle_against_recorded_reference_runs():
         h.update(kmers[order].tobytes())
         h.update(counts[order].tobytes())
         assert h.hexdigest() == r["oracle_counts_sha256"]
+
+
+def test_fasta_records_two_lines_per_record():
+    """FASTXreader<FASTAEntry> (FastXReader.h:97-116): every two non-empty lines are a record, the second is
+    the sequence.  The restatement against an independent dictionary count."""
+    import numpy as np
+    from conftest import python_counts
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(4)
+    recs = []
+    for r in range(60):
+        n = int(rng.integers(1, 120))
+        recs.append(b">r%d some description\n" % r + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n)) + b"\n")
+        if r % 7 == 0:
+            recs.append(b"\n")
+    text = b"".join(recs)
+    for k in (8, 21, 33):
+        exp = python_counts(text, k, 2)
+        o = Oracle(k, min(16, 2 * k - 1), 4, seed=1)
+        assert o.count_fastq(text, 2) == sum(exp.values())
+        assert o.distinct() == len(exp)
+        for kmer, c in list(exp.items())[:200]:
+            assert o.get_count(o.encode(kmer)) == c
+

@@ -107,6 +107,7 @@ def lib():
                                      ctypes.POINTER(ctypes.c_double), u64p]
     L.tsx_hip_get_stage_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double), u64p]
     L.tsx_hip_set_path.argtypes = [vp, ci]
+    L.tsx_hip_set_record_lines.argtypes = [vp, ci]
     L.tsx_hip_synth_fastq_device.argtypes = [u64, u64, u64, ci, vp, sz, u64p, u64p, u64p, ci, vp]
     _lib = L
     return L
@@ -303,6 +304,10 @@ class TSXHashMapHIP:
         ms, n = (ctypes.c_double * 6)(), ctypes.c_uint64(0)
         _check(self._lib.tsx_hip_get_stage_timing(self._h, ms, ctypes.byref(n)))
         return dict(zip(("line", "scan", "level1", "level2", "build", "gap"), [float(x) for x in ms])), int(n.value)
+
+    def set_record_lines(self, lines):
+        """4 = FASTQ records (default), 2 = FASTA as FASTXreader<FASTAEntry> reads it (tsx_hip_set_record_lines)."""
+        _check(self._lib.tsx_hip_set_record_lines(self._h, lines))
 
     def set_path(self, path):
         """0 auto, 1 atomic, 2 partitioned (tsx_hip_set_path)."""

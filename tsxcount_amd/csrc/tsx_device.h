@@ -75,6 +75,9 @@ struct TableParams {
     uint32_t shard;             // this GPU's slot range: home slots [shard << l, (shard + 1) << l)
     int g, groups;              // LUT granularity (4 or 8 bits) and group count
     uint32_t max_reprobes;
+    uint32_t line_mask;         // lines per record - 1: 3 = FASTQ (FASTQEntry, FastXReader.h:62-95), 1 = FASTA as
+                                // FASTXreader<FASTAEntry> reads it (two lines per record, :97-116); the sequence
+                                // is the line with (index & line_mask) == 1
     DeferList defer;            // see DeferList; set per launch by the host
 };
 

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
                 if (o) { m0 |= s_nl[w + 1] << (64 - o); m1 |= s_nl[w + 2] << (64 - o); }
                 const uint64_t need0 = (k >= 64) ? ~0ULL : ((1ULL << k) - 1ULL);
                 const uint64_t need1 = (k > 64) ? ((k >= 128) ? ~0ULL : ((1ULL << (k - 64)) - 1ULL)) : 0ULL;
-                const bool valid = ((line & 3u) == 1u) && ((m0 & need0) == 0) && ((m1 & need1) == 0) &&
+                const bool valid = ((line & p.line_mask) == 1u) && ((m0 & need0) == 0) && ((m1 & need1) == 0) &&
                                    (gpos + k <= n) && (gpos < own_end);
                 slot_of[j] = -1; direct_cnt[j] = 0;
                 // header, '+' and quality lines make up half of a FASTQ text: a wave whose 64
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
         const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
         const uint64_t g0 = base + s0;
         const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
-        const uint32_t vm = ~(uint32_t)r & b0 & ~b1 & ((1u << jmax) - 1u);   // line & 3 == 1, no newline, in range
+        const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;   // FASTA: every second line is a sequence
+        const uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);   // sequence line, no newline, in range
         added += (unsigned long long)__popc(vm);
         // header, '+' and quality lines are half of a FASTQ text: skip waves without a k-mer start
         if (__ballot(vm != 0u) == 0ULL) continue;
@@ -702,7 +703,8 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
         const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
         const uint64_t g0 = base + s0;
         const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
-        const uint32_t vm = ~(uint32_t)r[0] & b0 & ~b1 & ((1u << jmax) - 1u);   // line & 3 == 1, no newline, in range
+        const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;   // FASTA: every second line is a sequence
+        const uint32_t vm = ~(uint32_t)r[0] & b0 & nb1 & ((1u << jmax) - 1u);   // sequence line, no newline, in range
         added += (unsigned long long)__popc(vm);
         if (__ballot(vm != 0u) == 0ULL) continue;   // header, '+' and quality lines: nothing starts here
 

@@ -393,6 +393,7 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l, in
     const uint64_t maxr = (1ULL << p.R) - 1ULL;
     p.max_reprobes = (uint32_t)std::min<uint64_t>(maxr, p.slot_mask);
     p.top_mask = (p.n & 63) ? ((1ULL << (p.n & 63)) - 1ULL) : ~0ULL;
+    p.line_mask = 3;                 // FASTQ records (tsx_hip_set_record_lines)
     // LUT granularity: bytes when the table stays <= 32 KiB of LDS, nibbles otherwise
     const size_t lut8 = (size_t)((p.n + 7) / 8) * 256 * p.wk * 8;
     p.g = (lut8 <= (32u << 10)) ? 8 : 4;
@@ -885,7 +886,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         return TSX_HIP_OK;
     }
 
-    const uint64_t maxrec = own_end / 2 + 65536;
+    // FASTQ: the quality line is as long as the sequence, at most half of the bytes start a k-mer; FASTA: all may
+    const uint64_t maxrec = (p.line_mask == 3 ? own_end / 2 : own_end) + 65536;
     const uint32_t nown = 1u << (p.lg - p.l);
     // the scan kernels of this path keep one log region per WAVE
     const int scan_wgs = (p.wk == 1) ? SCAN_WG_PER_CU : 2;
@@ -992,7 +994,7 @@ extern "C" int tsx_hip_shard_send_capacity(tsx_hip_map *m, size_t text_bytes, si
     if (!m || !keys_out) return TSX_HIP_EINVAL;
     const uint64_t ntiles = (text_bytes + TILE - 1) / TILE;
     const int g = (int)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)m->cus * SCAN_WG_PER_CU)) * (NT / 64);
-    const uint64_t maxrec = text_bytes / 2 + 65536;
+    const uint64_t maxrec = (m->p.line_mask == 3 ? text_bytes / 2 : text_bytes) + 65536;
     const uint64_t log_cap = (maxrec / g + maxrec / g / 3 + 2048 + 1) & ~1ULL;
     *keys_out = (size_t)g * log_cap;
     return TSX_HIP_OK;
@@ -1077,6 +1079,12 @@ extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, c
     hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
                        (const uint64_t *)dev_counts, (uint64_t)n, (unsigned long long *)nullptr);
     HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_set_record_lines(tsx_hip_map *m, int lines) {
+    if (!m || (lines != 2 && lines != 4)) return TSX_HIP_EINVAL;
+    m->p.line_mask = (uint32_t)lines - 1u;
     return TSX_HIP_OK;
 }
 

@@ -104,6 +104,9 @@ public:
         return out;
     }
 
+    // FASTXreader<FASTAEntry> (FastXReader.h:97-116) reads two lines per record, FASTQEntry (:62-95) four
+    void setRecordLines(int iLines) { check(tsx_hip_set_record_lines(m_pMap, iLines)); }
+
     // countKMers body (main.cpp:104-218): whole FASTQ text -> table
     void countFastq(const char *pText, size_t iBytes) { check(tsx_hip_count_fastq_host(m_pMap, pText, iBytes)); }
 

@@ -21,7 +21,7 @@
 
 struct arguments {
     int k = 14, l = 26, storagebits = 4, threads = 0;  // main.cpp:410-413
-    std::string input_path, mode = "HIP";
+    std::string input_path, mode = "HIP", format;   // format: "", "fastq" or "fasta" ("" = by file name)
     bool check = false, checkabort = false;
     unsigned long long seed = 1;
     int device = 0;
@@ -35,8 +35,8 @@ static bool opt(const char *arg, const char *name, std::string &val) {
 }
 
 static int usage() {
-    std::cerr << "Usage: tsxCount --input=FASTQ[.gz] [--k=K] [--l=L] [--s=STORAGE] [--mode=HIP] [--threads=T]\n"
-                 "                [--check] [--checkabort] [--seed=S] [--device=D]\n"
+    std::cerr << "Usage: tsxCount --input=FASTQ|FASTA[.gz] [--k=K] [--l=L] [--s=STORAGE] [--mode=HIP] [--threads=T]\n"
+                 "                [--check] [--checkabort] [--seed=S] [--device=D] [--format=fastq|fasta]\n"
                  "Count k-mers on an MI355X. --check compares with FASTQ.<k>.count (kmer<TAB>count per line)."
               << std::endl;
     return 1;
@@ -82,6 +82,7 @@ int main(int argc, char *argv[]) {
         else if (opt(argv[i], "check", v)) a.check = true;
         else if (opt(argv[i], "checkabort", v)) a.checkabort = true;
         else if (opt(argv[i], "seed", v)) a.seed = strtoull(v.c_str(), nullptr, 10);
+        else if (opt(argv[i], "format", v)) a.format = v;
         else if (opt(argv[i], "device", v)) a.device = atoi(v.c_str());
         else if (opt(argv[i], "help", v)) return usage();
         else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << std::endl; return usage(); }
@@ -107,6 +108,13 @@ int main(int argc, char *argv[]) {
         std::cerr << "Creating TSXHashMap HIP" << std::endl;
         TSXHashMapHIP oMap((uint8_t)a.l, (uint32_t)a.storagebits, (uint16_t)a.k, (uint8_t)a.threads, a.seed, a.device);
 
+        {   // FASTA (two lines per record, FASTXreader<FASTAEntry>) by option or by file name
+            std::string stem = a.input_path;
+            if (stem.size() > 3 && stem.rfind(".gz") == stem.size() - 3) stem.resize(stem.size() - 3);
+            auto ends = [&](const char *suf) { const std::string x(suf); return stem.size() >= x.size() && stem.compare(stem.size() - x.size(), x.size(), x) == 0; };
+            const bool fasta = a.format == "fasta" || (a.format.empty() && (ends(".fa") || ends(".fasta") || ends(".fna")));
+            if (fasta) { oMap.setRecordLines(2); std::cerr << "Format=FASTA (2 lines per record)" << std::endl; }
+        }
         std::vector<char> owned;
         const char *text = nullptr;
         size_t n = 0;
