@@ -30,9 +30,9 @@ static thread_local std::string g_last_error;
         }                                                                                \
     } while (0)
 
-static int scan_wg_per_cu() {  // scan_log_kernel workgroups per CU: 4 are resident (128 VGPRs, 28 KiB LDS)
+static int scan_wg_per_cu() {  // scan_log_kernel workgroups per CU: 5 are resident (88 VGPRs, 28 KiB LDS); 4: +0.35 ms
     static int v = 0;
-    if (!v) { v = 4; if (const char *e = getenv("TSX_HIP_SCAN_WGS")) v = std::min(16, std::max(1, atoi(e))); }
+    if (!v) { v = 5; if (const char *e = getenv("TSX_HIP_SCAN_WGS")) v = std::min(16, std::max(1, atoi(e))); }
     return v;
 }
 #define SCAN_WG_PER_CU scan_wg_per_cu()
@@ -733,6 +733,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_WPT / nb);
         uint32_t bits = 4;
         while ((1u << bits) < PART_FLUSH + 2 * mean && bits < 6) ++bits;
+        if (const char *e = getenv("TSX_HIP_RING_BITS")) bits = (uint32_t)std::min(6, std::max(4, atoi(e)));   // experiments
         return bits;
     };
     auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 36); };
