@@ -1019,4 +1019,189 @@ __global__ __launch_bounds__(1024) void build_segments_wide_kernel(TableParams p
     }
 }
 
+// ---- the wave-stream build for multi-limb keys and slots ------------------------------------------------
+// build_segments_wide_kernel above has the disease build_segments_kernel had (a per-lane load in flight that
+// the wave waits for in nearly every round).  Same cure as build_segments_stream_kernel: a wave owns a stream of
+// batches of 64 records, loaded up front into registers (BKW batches of RW words per wave and pass); the batch
+// being consumed sits in the wave's own slice of LDS behind the segment (64 records; a round hands out keys of
+// that one batch only), a lane that has placed its key takes the next record of it.  The slot protocol is the
+// wide kernel's: limb 0 claimed by CAS with LOCK, limbs 1..W-1 written, limb 0 stored without LOCK.
+template <int RW> struct WideBatches { static constexpr int value = (RW == 1) ? 16 : (RW == 2) ? 12 : 6; };
+
+template <int WK>
+__global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableParams p, const uint64_t *lists,
+                                                                          const unsigned long long *list_start,
+                                                                          const unsigned long long *list_cnt,
+                                                                          uint64_t list_cap, uint32_t pieces, uint32_t nseg,
+                                                                          int fresh) {
+    constexpr int RW = RecWords<WK>::value;
+    constexpr int BKW = WideBatches<RW>::value;
+    extern __shared__ uint64_t s_seg[];  // 2^S slots of W words, then 64 records per wave
+    const uint32_t W = (uint32_t)p.W;
+    const uint32_t nwords = (1u << p.S) * W;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint64_t *ring = s_seg + nwords + wave * (64u * RW);
+    const uint32_t npieces = list_start ? 1u : pieces;
+    const uint32_t nw = (nt / 64u) / npieces;          // waves per list (pieces is a power of two <= 8)
+    const uint32_t grp = wave / nw, wi = wave % nw;
+    const uint32_t smask = (uint32_t)p.seg_mask;
+    const uint64_t k0mask = p.k0mask, lock = p.lock_bit;
+    const uint32_t maxr = p.max_reprobes;
+    const uint64_t one = 1ULL << p.cshift;
+
+    auto my_list = [&](uint32_t seg, const uint64_t *&base) -> uint32_t {
+        if (list_start) { base = lists + (uint64_t)list_start[seg] * RW; return (uint32_t)list_cnt[seg]; }
+        base = lists + ((uint64_t)seg * pieces + grp) * list_cap * RW;
+        return (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + grp], list_cap);
+    };
+    auto seg_keys = [&](uint32_t seg) -> uint64_t {
+        if (list_start) return (uint64_t)list_cnt[seg];
+        uint64_t n = 0;
+        for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
+        return n;
+    };
+
+    uint64_t B[BKW][RW];
+    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const uint64_t n = seg_keys(seg);
+        uint64_t *slots = p.table + ((uint64_t)seg << p.S) * W;
+        if (n == 0) {
+            if (fresh) {
+                for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+                    *reinterpret_cast<uint4 *>(&slots[i]) = make_uint4(0, 0, 0, 0);
+                if (tid == 0) p.seg_dirty[seg] = 0;
+            }
+            continue;
+        }
+        const bool dirty = !fresh && p.seg_dirty[seg] != 0;
+        const uint64_t *base;
+        const uint32_t mine = my_list(seg, base);
+        auto load_pass = [&](uint32_t pass) {
+#pragma unroll
+            for (int j = 0; j < BKW; ++j) {
+                const uint32_t idx = (wi + (pass * BKW + (uint32_t)j) * nw) * 64u + lane;
+                if (idx < mine) load_rec<RW>(base + (uint64_t)idx * RW, B[j]);
+                else {
+#pragma unroll
+                    for (int t = 0; t < RW; ++t) B[j][t] = 0;
+                }
+            }
+        };
+        load_pass(0);
+        lds_barrier();  // previous segment fully written out
+        if (dirty) {
+            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
+        } else {
+            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+                *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
+        }
+        lds_barrier();
+        const uint32_t npass = ((mine + 63u) / 64u + nw * BKW - 1u) / (nw * BKW);
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+            if (pass > 0) load_pass(pass);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // the batches have arrived: the one wait for loads of this pass
+            uint32_t cb = 0;        // batch of the pass that sits in the ring
+            uint32_t blen = 0;      // its length
+            uint32_t off = 0;       // records of it handed out
+            auto stage = [&](uint32_t j) {   // batch j of the pass -> ring (j wave-uniform); returns its length
+                const uint32_t first = (wi + (pass * BKW + j) * nw) * 64u;
+                const uint32_t len = (j < (uint32_t)BKW && first < mine) ? min(64u, mine - first) : 0u;
+                if (len) {
+                    uint64_t r[RW];
+#pragma unroll
+                    for (int t = 0; t < RW; ++t) r[t] = 0;
+#pragma unroll
+                    for (int jj = 0; jj < BKW; ++jj)
+                        if ((uint32_t)jj == j) {
+#pragma unroll
+                            for (int t = 0; t < RW; ++t) r[t] = B[jj][t];
+                        }
+                    store_rec<RW>(ring + (uint64_t)lane * RW, r);
+                }
+                return len;
+            };
+            blen = stage(0);
+            uint64_t e0 = 0, hi[4] = {0, 0, 0, 0};
+            uint32_t i = 0, q = 0, spins = 0;   // i == 0: the lane holds no key
+            for (;;) {
+                // ---- hand records of the staged batch to the lanes that hold none
+                if (off < blen) {
+                    const unsigned long long nm = __ballot(i == 0u);
+                    if (nm) {
+                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+                        if (i == 0u && off + pre < blen) {
+                            uint64_t rec[RW], h[WK], pos0;
+                            load_rec<RW>(ring + (uint64_t)(off + pre) * RW, rec);
+#pragma unroll
+                            for (int t = 0; t < WK; ++t) h[t] = rec[t];
+                            split_key<WK>(p, h, pos0, e0, hi);
+                            i = 1u;
+                            spins = 0;
+                            q = ((uint32_t)pos0 + 1u) & smask;
+                        }
+                        const uint32_t got = min((uint32_t)__builtin_popcountll(nm), blen - off);
+                        off = __builtin_amdgcn_readfirstlane(off + got);
+                    }
+                }
+                if (off >= blen && blen) {   // the staged batch is used up (its reads are ahead of this write in LDS order)
+                    cb = __builtin_amdgcn_readfirstlane(cb + 1u);
+                    off = 0;
+                    blen = stage(cb);
+                }
+                if (__ballot(i != 0u) == 0ULL) {
+                    if (blen == 0) break;   // stream dry and every key placed
+                    continue;
+                }
+                // ---- one probe for every lane that holds a key
+                if (i != 0u) {
+                    unsigned long long *slot = reinterpret_cast<unsigned long long *>(&s_seg[(size_t)q * W]);
+                    const uint64_t key0 = e0 | i;
+                    const unsigned long long old = atomicCAS(slot, 0ULL, (unsigned long long)(key0 | lock | one));
+                    bool placed = false, next = false;
+                    if (old == 0ULL) {
+                        if (W > 1) {
+                            for (uint32_t t = 1; t < W; ++t) slot[t] = hi[t - 1];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                            __hip_atomic_store(slot, (unsigned long long)(key0 | one), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        placed = true;
+                    } else if ((old & k0mask) != key0) {
+                        next = true;
+                    } else if (W > 1 && (old & lock)) {
+                        // claimed, limbs not published yet: probe the same slot again in the next round (bounded)
+                        if (++spins > (1u << 20)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); spins = 0; next = true; }
+                    } else {
+                        bool same = true;
+                        if (W > 1) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            for (uint32_t t = 1; t < W; ++t) same &= (slot[t] == hi[t - 1]);
+                        }
+                        if (same) {
+                            const unsigned long long prev = atomicAdd(slot, (unsigned long long)one);
+                            const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
+                            if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
+                            placed = true;
+                        } else {
+                            next = true;
+                        }
+                    }
+                    if (next) {
+                        if (i >= maxr) { atomicAdd(&p.stats[ST_FAIL], 1ULL); placed = true; }
+                        ++i;
+                        q = (q + i) & smask;
+                    }
+                    if (placed) i = 0u;
+                }
+            }
+        }
+        lds_barrier();
+        for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
+            *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);
+        if (tid == 0) p.seg_dirty[seg] = 1;
+    }
+}
+
 }  // namespace tsx

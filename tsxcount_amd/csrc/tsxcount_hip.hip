@@ -701,6 +701,10 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         m->attr_done = true;
@@ -799,6 +803,11 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
                                lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
+        } else if (build_v == 2) {   // multi-limb keys and / or slots: wave streams too (64 records of LDS per wave behind the segment)
+            const size_t ring_bytes = (size_t)16 * 64 * 8 * rw;
+            DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_stream_kernel<WKV>), dim3(gb), dim3(1024),
+                                              seg_bytes + ring_bytes, st, pp, lists, lists_start, lists_cnt, lists_cap, pieces,
+                                              pl.nseg, fresh));
         } else {
             DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_kernel<WKV>), dim3(gb), dim3(bnt), seg_bytes, st, pp,
                                               lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh));
