@@ -151,12 +151,12 @@ int tsx_hip_set_timing(tsx_hip_map *m, int enable);
 int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
                        uint64_t *launches);
 /*
- * The same accumulation split per stage: stage_ms[6] = line passes, scan kernel
- * (count_fastq_kernel or scan_log_kernel), radix level 1 (offsets + partition; in a
- * sharded run also the histogram of the received keys), radix level 2, segment build,
- * and the gap between the end of the scan and the start of the partition phase (0
- * except in a sharded run, where the owner split and the key exchange lie there).
- * Levels and build are 0 on the atomic path.  Either get_* call resets the accumulation.
+ * The same accumulation split per stage: stage_ms[7] = line passes, scan kernel
+ * (count_fastq_kernel or scan_log_kernel), radix level 1 (offsets + partition; in a sharded run also the
+ * histogram of the received keys), radix level 2, the segment build kernel, the gap between the end of the
+ * scan and the start of the partition phase (0 except in a sharded run, where the owner split and the key
+ * exchange lie there), and the inserts that wait for the build (overflow queues, deferred list).
+ * Levels, build and inserts are 0 on the atomic path.  Either get_* call resets the accumulation.
  */
 int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64_t *launches);
 /*

@@ -338,7 +338,7 @@ def test_stage_timing_hooks(T):
     m.set_timing(True)
     m.countFastq(text)
     stage, pieces = m.get_stage_timing()
-    assert pieces >= 1 and set(stage) == {"line", "scan", "level1", "level2", "build", "gap"}
+    assert pieces >= 1 and set(stage) == {"line", "scan", "level1", "level2", "build", "gap", "post"}
     assert stage["scan"] > 0 and stage["level1"] > 0 and stage["build"] > 0
     assert stage["level2"] < 0.2 * stage["level1"]   # l=22: one radix level, two events back to back
     m.set_path("atomic")

@@ -299,11 +299,12 @@ class TSXHashMapHIP:
         return a.value, b.value, c.value, int(n.value)
 
     def get_stage_timing(self):
-        """({stage: ms}, pieces) since the last call; stages: line, scan, level1, level2, build, gap
-        (gap = scan end to partition start: the owner split and the key exchange of a sharded run)."""
-        ms, n = (ctypes.c_double * 6)(), ctypes.c_uint64(0)
+        """({stage: ms}, pieces) since the last call; stages: line, scan, level1, level2, build, gap, post
+        (gap = scan end to partition start: the owner split and the key exchange of a sharded run;
+        post = overflow queues + deferred list, inserted after the build kernel)."""
+        ms, n = (ctypes.c_double * 7)(), ctypes.c_uint64(0)
         _check(self._lib.tsx_hip_get_stage_timing(self._h, ms, ctypes.byref(n)))
-        return dict(zip(("line", "scan", "level1", "level2", "build", "gap"), [float(x) for x in ms])), int(n.value)
+        return dict(zip(("line", "scan", "level1", "level2", "build", "gap", "post"), [float(x) for x in ms])), int(n.value)
 
     def set_record_lines(self, lines):
         """4 = FASTQ records (default), 2 = FASTA as FASTXreader<FASTAEntry> reads it (tsx_hip_set_record_lines)."""

@@ -93,6 +93,8 @@ struct tsx_hip_map {
 };
 
 static const size_t STAGE_PAD = 256;
+static const int EV_N = 8;   // timing events per piece: before pass 1, before the scan, after it, start of the partition
+                             // phase, after level 1, after level 2, after the build kernel, after the inserts behind it
 static bool can_partition(const tsx_hip_map *m);
 static int clear_impl(tsx_hip_map *m, bool full);
 static int ensure_zeroed(tsx_hip_map *m, hipStream_t st);
@@ -815,6 +817,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         HIP_TRY(hipGetLastError());
         m->fresh = false;   // every segment has been written: built, or zeroed
     }
+    if (ev) HIP_TRY(hipEventRecord(ev[6], st));
     // Records that found their sub-list filled up by a hot key, and the deferred list: inserted now, by the
     // whole chip, into a table whose segments are all in place.
     if (nq2 && !(m->dbg & 1)) {
@@ -861,10 +864,10 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     hipEvent_t *ev = nullptr;
     if (m->timing) {
-        if (m->ev_used + 7 > m->ev.size()) {
-            for (int i = 0; i < 7; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
+        if (m->ev_used + EV_N > m->ev.size()) {
+            for (int i = 0; i < EV_N; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); m->ev.push_back(e); }
         }
-        ev = &m->ev[m->ev_used]; m->ev_used += 7;
+        ev = &m->ev[m->ev_used]; m->ev_used += EV_N;
         HIP_TRY(hipEventRecord(ev[0], st));
     }
     const int g1 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8);
@@ -892,7 +895,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         DISPATCH_WK(m, hipLaunchKernelGGL((count_fastq_kernel<WKV>), dim3(g3), dim3(NT), lut_bytes, st, m->p, d_text, n,
                                           own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg));
         HIP_TRY(hipGetLastError());
-        if (ev) for (int i = 2; i < 7; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+        if (ev) for (int i = 2; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
         return TSX_HIP_OK;
     }
 
@@ -956,10 +959,10 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         if (rc != TSX_HIP_OK) return rc;
     }
     if (ev && shard_send) {   // the partition phase follows in tsx_hip_shard_build_device, which records 3..6 again
-        for (int i = 3; i < 7; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+        for (int i = 3; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
         m->ev_open.push_back((long)(ev - m->ev.data()));
     }
-    if (ev && !shard_send) HIP_TRY(hipEventRecord(ev[6], st));
+    if (ev && !shard_send) HIP_TRY(hipEventRecord(ev[7], st));
     return TSX_HIP_OK;
 }
 
@@ -1055,7 +1058,7 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
     HIP_TRY(hipMemcpyAsync(pl.c_rstart, m->h_regions.data(), (size_t)g * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(pl.c_log, m->h_regions.data() + g, (size_t)g * 8, hipMemcpyHostToDevice, st));
     hipEvent_t *ev = nullptr;
-    if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + 7 <= m->ev_used) {
+    if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
         ev = &m->ev[(size_t)m->ev_open.front()];
         HIP_TRY(hipEventRecord(ev[3], st));   // the histogram of the received keys counts as level 1
     }
@@ -1064,7 +1067,7 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
                        pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
     HIP_TRY(hipGetLastError());
     rc = run_partition_build(m, pl, keys, pl.c_rstart, 0, st, ev);
-    if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[6], st));
+    if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[7], st));
     return rc;
 }
 
@@ -1115,18 +1118,19 @@ extern "C" int tsx_hip_set_timing(tsx_hip_map *m, int enable) {
 extern "C" int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64_t *launches) {
     if (!m) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    static const int from[6] = {0, 1, 3, 4, 5, 2}, to[6] = {1, 2, 4, 5, 6, 3};  // line, scan, level 1, level 2, build, gap
-    for (size_t i = 0; i + 7 <= m->ev_used; i += 7) {
-        HIP_TRY(hipEventSynchronize(m->ev[i + 6]));
-        for (int sgm = 0; sgm < 6; ++sgm) {
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    // line, scan, level 1, level 2, build kernel, gap, inserts after the build (overflow queues + deferred list)
+    static const int from[7] = {0, 1, 3, 4, 5, 2, 6}, to[7] = {1, 2, 4, 5, 6, 3, 7};
+    for (size_t i = 0; i + EV_N <= m->ev_used; i += EV_N) {
+        HIP_TRY(hipEventSynchronize(m->ev[i + 7]));
+        for (int sgm = 0; sgm < 7; ++sgm) {
             float t = 0;
             HIP_TRY(hipEventElapsedTime(&t, m->ev[i + from[sgm]], m->ev[i + to[sgm]]));
             acc[sgm] += t;
         }
     }
-    if (stage_ms) for (int sgm = 0; sgm < 6; ++sgm) stage_ms[sgm] = acc[sgm];
-    if (launches) *launches = m->ev_used / 7;
+    if (stage_ms) for (int sgm = 0; sgm < 7; ++sgm) stage_ms[sgm] = acc[sgm];
+    if (launches) *launches = m->ev_used / EV_N;
     m->ev_used = 0;
     m->ev_open.clear();
     return TSX_HIP_OK;
@@ -1134,12 +1138,12 @@ extern "C" int tsx_hip_get_stage_timing(tsx_hip_map *m, double *stage_ms, uint64
 
 extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double *build_ms,
                                   uint64_t *launches) {
-    double sgm[6];
+    double sgm[7];
     const int rc = tsx_hip_get_stage_timing(m, sgm, launches);
     if (rc != TSX_HIP_OK) return rc;
     if (line_ms) *line_ms = sgm[0];
     if (count_ms) *count_ms = sgm[1];
-    if (build_ms) *build_ms = sgm[2] + sgm[3] + sgm[4];
+    if (build_ms) *build_ms = sgm[2] + sgm[3] + sgm[4] + sgm[6];
     return TSX_HIP_OK;
 }
 
