@@ -298,8 +298,8 @@ def main():
         names = {"scan": ("scan_log_kernel" if m.wk == 1 else "scan_log_wide_kernel<%d>" % m.wk) if partitioned
                  else "count_fastq_kernel<%d>" % m.wk,
                  "level1": "partition_ring_kernel (level 1)", "level2": "partition_ring_kernel (level 2)",
-                 "build": "build_segments_kernel" if (m.wk == 1 and m.layout.entry_limbs == 1)
-                 else "build_segments_wide_kernel<%d>" % m.wk}
+                 "build": "build_segments_stream_kernel" if (m.wk == 1 and m.layout.entry_limbs == 1)
+                 else "build_segments_wide_stream_kernel<%d>" % m.wk}
         stage_ms = {k2: stage[k2] / pieces for k2 in names}
         dom = max(stage_ms, key=lambda k2: stage_ms[k2])   # the kernel a step spends most time in
         kern_ms = stage_ms[dom]
