@@ -7,11 +7,11 @@ run() {
 import json
 try:
     d=json.load(open("gpurun_out/mx_$tag.json"))
-    print("$tag", round(d["ms_per_step"],2),"ms", d["config"]["check"], {s:round(x["ms"],2) for s,x in d["roofline"]["stages"].items()}, d["config"].get("check_detail",{}).get("failure_counters"))
+    print("$tag", round(d["ms_per_step"],2),"ms", d["config"]["check"], {s:round(x["ms"],2) for s,x in d["roofline"]["stages"].items()})
 except Exception as e: print("$tag ERR", e)
 PY
 }
-run base X=1
-run ring4 TSX_HIP_RING_BITS=4
-run ring6 TSX_HIP_RING_BITS=6
-run cpr4 TSX_HIP_CPR2=4
+run la1 TSX_HIP_BUILD_LOOKAHEAD=1
+run la2 TSX_HIP_BUILD_LOOKAHEAD=2
+run la3 TSX_HIP_BUILD_LOOKAHEAD=3
+run la1b TSX_HIP_BUILD_LOOKAHEAD=1

@@ -795,13 +795,15 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         // off by default: it saves 0.1 ms of 6.3 but the prefetched lines rarely survive in L2 until they are
         // used -- the key lists are then read from HBM twice (12.6 GB instead of 6.5 GB, profiles/README.md)
         if (build_pf < 0) { const char *e = getenv("TSX_HIP_BUILD_PREFETCH"); build_pf = e ? atoi(e) : 0; }
+        static int build_la = -1;   // TSX_HIP_BUILD_LOOKAHEAD=0|1: the tail's look-ahead over the next probe positions
+        if (build_la < 0) { const char *e = getenv("TSX_HIP_BUILD_LOOKAHEAD"); build_la = e ? atoi(e) : 1; }
         if (p.wk == 1 && p.W == 1 && build_v == 2) {
             if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
                 hipLaunchKernelGGL((build_segments_stream_kernel<true>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_pf);
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_pf, build_la);
             else
                 hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_pf);
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_pf, build_la);
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
                                lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
