@@ -25,7 +25,8 @@
 namespace tsx {
 
 constexpr int PART_NT = 256;
-constexpr int PART_WPT = 8;      // words per thread per batch (8 / RW records)
+constexpr int RING_NT = 512;    // threads of a partition_ring_kernel workgroup: 16 waves per CU with two workgroups (256: 8 waves, level 2 3.5 ms; 1024: 4.1 ms)
+constexpr int PART_WPT = 4;     // words per thread per batch (4 / RW records)
 constexpr int PART_FLUSH = 16;   // words per burst (128 B = one L2 line)
 
 template <int RW>
@@ -79,12 +80,12 @@ constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
 
 constexpr int PART_ITER = 4;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
 template <int RW>
-__global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
+__global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap) {
-    constexpr int RPT = PART_WPT / RW;                 // records per thread per batch
+    constexpr int RPT = (PART_WPT >= RW) ? PART_WPT / RW : 1;   // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     if (tid < 2) s_njobs[tid] = 0;
     if (tid == 0) s_ovn = 0;
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap * RW : nullptr;
-    for (uint32_t b = tid; b < nb; b += PART_NT) {
+    for (uint32_t b = tid; b < nb; b += RING_NT) {
         s_tail[b] = 0; s_head[b] = 0;
         if (offs) { s_cur[b] = (offs_base[b] + offs[(size_t)b * nregions + r]) * RW; s_lim[b] = ~0ULL; }
         else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap * RW; s_lim[b] = s_cur[b] + dst_cap * RW; }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     lds_barrier();
     const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);   // records
     const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap) * RW;
-    constexpr uint64_t BATCH_REC = (uint64_t)PART_NT * RPT;
+    constexpr uint64_t BATCH_REC = (uint64_t)RING_NT * RPT;
     const uint64_t stride = (uint64_t)cpr * BATCH_REC;
 
     // TableParams is the first kernel argument: the slow paths read it from the argument segment
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         const uint32_t par = round & 1u;
         ++round;
         if (tid == 0) s_njobs[par ^ 1u] = 0;   // next round's counter: nobody reads or writes it in this round
-        for (uint32_t b = tid; b < nb; b += PART_NT) {  // (A)
+        for (uint32_t b = tid; b < nb; b += RING_NT) {  // (A)
             const uint32_t head = s_head[b];
             const uint32_t tail = min(s_tail[b], head + CAP);  // arrivals past the ring went out directly
             const uint32_t avail = tail - head;
@@ -194,18 +195,18 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         const uint32_t oct = tid >> 3, ol = tid & 7;  // (B): an octet of lanes per job
         if (dbg & 512) return;  // ablation: bookkeeping only
         const uint32_t njobs = s_njobs[par];
-        for (uint32_t j0 = 0; j0 < njobs; j0 += PART_ITER * (PART_NT / 8)) {
+        for (uint32_t j0 = 0; j0 < njobs; j0 += PART_ITER * (RING_NT / 8)) {
             unsigned long long meta[PART_ITER], lim[PART_ITER];
             uint32_t bj[PART_ITER];
             uint64_t k0[PART_ITER], k1[PART_ITER];
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (PART_NT / 8);
+                const uint32_t j = j0 + oct + u * (RING_NT / 8);
                 bj[u] = (j < njobs) ? s_job[j] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (PART_NT / 8);
+                const uint32_t j = j0 + oct + u * (RING_NT / 8);
                 meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
                 lim[u] = (j < njobs) ? s_lim[bj[u]] : 0ULL;
             }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     uint64_t base = (uint64_t)c * BATCH_REC;
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const uint64_t i = base + (uint64_t)q * PART_NT + tid;
+        const uint64_t i = base + (uint64_t)q * RING_NT + tid;
         if (i < n) load_rec<RW>(in + i * RW, cur[q]);
         else {
 #pragma unroll
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     for (; base < n; base += stride) {
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint64_t i = base + stride + (uint64_t)q * PART_NT + tid;
+            const uint64_t i = base + stride + (uint64_t)q * RING_NT + tid;
             if (i < n) load_rec<RW>(in + i * RW, nxt[q]);
             else {
 #pragma unroll
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         uint32_t bq[RPT], slot[RPT], head[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * PART_NT + tid;
+            const uint64_t i = base + (uint64_t)q * RING_NT + tid;
             bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
             slot[q] = (i < n) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
         }
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
         for (int q = 0; q < RPT; ++q) head[q] = s_head[bq[q]];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * PART_NT + tid;
+            const uint64_t i = base + (uint64_t)q * RING_NT + tid;
             if (i < n) {
                 const uint32_t b = bq[q];
                 if (slot[q] - head[q] < CAP) {   // RW | CAP and records are RW-aligned: a record never wraps
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(PART_NT) void partition_ring_kernel(
     flush(true);
     lds_barrier();
     if (dst_cnt)
-        for (uint32_t b = tid; b < nb; b += PART_NT) {
+        for (uint32_t b = tid; b < nb; b += RING_NT) {
             const uint64_t li = ((uint64_t)r * nb + b) * cpr + c;
             dst_cnt[li] = (min(s_cur[b], s_lim[b]) - li * dst_cap * RW) / RW;
         }
@@ -745,24 +746,37 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
     const uint32_t maxr = p.max_reprobes;
     const uint64_t one = 1ULL << p.cshift;
 
-    // this wave's list of segment `seg`: where it starts and how many keys it holds
-    auto my_list = [&](uint32_t seg, const uint64_t *&base) -> uint32_t {
-        if (list_start) { base = lists + (uint64_t)list_start[seg]; return (uint32_t)list_cnt[seg]; }
-        base = lists + ((uint64_t)seg * pieces + grp) * list_cap;
-        return (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + grp], list_cap);
+    // Sizes of the lists of segment `seg`: lane c holds the size of piece c (one load for the wave, not one
+    // after the other), seg_total adds them up, my_list picks this wave group's.
+    auto list_sizes = [&](uint32_t seg) -> uint32_t {
+        if (list_start) return lane == 0u ? (uint32_t)list_cnt[seg] : 0u;
+        return lane < pieces ? (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + lane], list_cap) : 0u;
     };
-    auto seg_keys = [&](uint32_t seg) -> uint64_t {
-        if (list_start) return (uint64_t)list_cnt[seg];
-        uint64_t n = 0;
-        for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
-        return n;
+    auto seg_total = [&](uint32_t c) -> uint32_t {   // pieces <= 8
+        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    auto my_list = [&](uint32_t seg, uint32_t c, const uint64_t *&base) -> uint32_t {
+        if (list_start) { base = lists + (uint64_t)list_start[seg]; return __builtin_amdgcn_readfirstlane(c); }
+        base = lists + ((uint64_t)seg * pieces + grp) * list_cap;
+        return __builtin_amdgcn_readlane(c, grp);
     };
 
     uint64_t B[BK];
     uint32_t pf = 0;   // the dword this lane prefetched for the next segment
+    // The first batches of the NEXT segment are loaded as soon as this wave's stream is dry (the batch registers
+    // are free then) and arrive while the wave probes for its last keys and the segment is written out: a segment
+    // costs ~23 us, of which the list sizes (scalar loads) and the keys (one HBM latency) used to be waited for
+    // in the open at its start.
+    uint32_t nx_seg = 0xFFFFFFFFu, nx_mine = 0;   // wave-uniform: the segment whose pass-0 batches B holds
+    uint64_t nx_n = 0;
+    const uint64_t *nx_base = nullptr;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
         asm volatile("" ::"v"(pf));   // the prefetch is 'used' here, a segment after it was issued
-        const uint64_t n = seg_keys(seg);
+        const bool have = (nx_seg == seg);
+        uint32_t sizes = 0;
+        if (!have) sizes = list_sizes(seg);
+        const uint64_t n = have ? nx_n : seg_total(sizes);
         uint64_t *slots = p.table + ((uint64_t)seg << p.S);
         if (n == 0) {
             if (fresh) {   // nothing to insert, but the stale slots must go
@@ -773,9 +787,16 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
             continue;
         }
         const bool dirty = !fresh && p.seg_dirty[seg] != 0;
-        const uint64_t *base;
-        const uint32_t mine = my_list(seg, base);
-        load_batches(base, mine, wi, nw, 0, lane, B);   // (L2 hits: the previous segment's pass prefetched them)
+        const uint64_t *base = nx_base;
+        uint32_t mine = nx_mine;
+        if (!have) {
+            mine = my_list(seg, sizes, base);
+            load_batches(base, mine, wi, nw, 0, lane, B);
+        }
+        // the next segment's list sizes: on their way now, looked at when the stream is dry
+        const uint32_t seg2 = seg + gridDim.x;
+        uint32_t sizes2 = 0;
+        if (seg2 < nseg) sizes2 = list_sizes(seg2);
         lds_barrier();  // previous segment fully written out
         if (dirty) {
             for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
@@ -800,12 +821,11 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
             ring[128u + lane] = B[2];
             ring[192u + lane] = B[3];
             if (pass == 0) {
-                // the next segment's lists start towards L2 now and stay in flight while this segment is
-                // inserted and written out: lane L of the lanes that share a list touches line L of it
+                // (optional, off: the next segment's lists towards L2 -- the key lists are then read twice)
                 const uint32_t nseg2 = seg + gridDim.x;
                 if (prefetch && nseg2 < nseg) {
                     const uint64_t *base2;
-                    const uint32_t mine2 = my_list(nseg2, base2);
+                    const uint32_t mine2 = my_list(nseg2, sizes2, base2);
                     const uint32_t line = (wi * 64u + lane) * 16u;             // first key of this lane's line
                     if (line < mine2) pf = *reinterpret_cast<const uint32_t *>(base2 + line);
                 }
@@ -818,34 +838,8 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
             uint32_t i = 0, q = 0;
             unsigned long long d_rounds = 0, d_t0 = 0;
             if (DIAG && (dbg & 16)) d_t0 = __builtin_amdgcn_s_memtime();
-            for (;;) {
-                // ---- hand the next keys of the stream to the lanes that hold none
-                if (taken < total) {
-                    const unsigned long long nm = __ballot(i == 0u);
-                    if (nm) {
-                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-                        const uint32_t pp = off + pre;   // relative to batch cb: 0..126
-                        // consecutive stream positions = consecutive words of the ring: no bank conflicts
-                        const uint64_t kf = ring[(((cb + (pp >> 6)) & 3u) << 6) + (pp & 63u)];
-                        if (i == 0u && taken + pre < total) {
-                            i = 1u;
-                            q = ((uint32_t)kf + 1u) & smask;                    // q_1 = q_0 + 1
-                            e0 = ((kf >> sh_lg) << sh_r) & k0mask;              // split_key for WK = 1
-                        }
-                        const uint32_t got = min((uint32_t)__builtin_popcountll(nm), total - taken);
-                        taken = __builtin_amdgcn_readfirstlane(taken + got);
-                        off = __builtin_amdgcn_readfirstlane(off + got);
-                        if (off >= 64u) {   // batch cb is used up: its quarter of the ring takes batch cb + 4
-                            off -= 64u;
-                            cb = __builtin_amdgcn_readfirstlane(cb + 1u);
-                            ring[(((cb + 3u) & 3u) << 6) + lane] = pick_batch(B, cb + 3u);
-                        }
-                    }
-                }
-                if (__ballot(i != 0u) == 0ULL) break;   // stream dry and every key placed
-                if (DIAG) ++d_rounds;
-                // ---- one probe for every lane that holds a key
+            // one probe for every lane that holds a key
+            auto probe = [&]() {
                 if (i != 0u) {
                     const uint64_t key0 = e0 | i;
                     const unsigned long long old =
@@ -867,25 +861,65 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                     q = (q + i) & smask;
                     if (placed) i = 0u;
                 }
-                // ---- the tail.  Once the stream is dry the wave works on its last keys only, and they meet the
-                // segment at its final load: the longest of the ~2000 probe chains in flight is ~25 probes, ~16 rounds
-                // of a wave's ~38 run with a handful of lanes.  A lane that is still probing looks at its next three
-                // probe positions as well (plain reads, issued together) and steps over those that hold ANOTHER key:
-                // slots never become empty again, so a slot seen taken by someone else stays out of the question; a
-                // slot seen empty or holding this key is where the next round's CAS goes.
-                // (Seven positions instead of three: no better, 6.04 vs 5.97 ms; looking ahead in every round, not only
-                // in the tail: worse, 6.73 ms -- the main phase is bound by instruction issue.)
-                if (taken >= total && look_ahead) {
-                    if (i != 0u && i + 3u < maxr) {
-                        const uint32_t q1 = (q + i + 1u) & smask, q2 = (q1 + i + 2u) & smask, q3 = (q2 + i + 3u) & smask;
-                        const uint64_t v0 = s_seg[q], v1 = s_seg[q1], v2 = s_seg[q2];
-                        const bool t0 = v0 != 0 && (v0 & k0mask) != (e0 | i);
-                        const bool t1 = t0 && v1 != 0 && (v1 & k0mask) != (e0 | (i + 1u));
-                        const bool t2 = t1 && v2 != 0 && (v2 & k0mask) != (e0 | (i + 2u));
-                        if (t2) { i += 3u; q = q3; }
-                        else if (t1) { i += 2u; q = q2; }
-                        else if (t0) { i += 1u; q = q1; }
+            };
+            // ---- main phase: hand the next keys of the stream to the lanes that hold none, then probe.  After a
+            // hand-out at least one lane holds a key: no exit test in here.
+            while (taken < total) {
+                const unsigned long long nm = __ballot(i == 0u);
+                if (nm) {
+                    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+                    const uint32_t pp = off + pre;   // relative to batch cb: 0..126
+                    // consecutive stream positions = consecutive words of the ring: no bank conflicts
+                    const uint64_t kf = ring[(((cb + (pp >> 6)) & 3u) << 6) + (pp & 63u)];
+                    if (i == 0u && taken + pre < total) {
+                        i = 1u;
+                        q = ((uint32_t)kf + 1u) & smask;                    // q_1 = q_0 + 1
+                        e0 = ((kf >> sh_lg) << sh_r) & k0mask;              // split_key for WK = 1
                     }
+                    const uint32_t got = min((uint32_t)__builtin_popcountll(nm), total - taken);
+                    taken = __builtin_amdgcn_readfirstlane(taken + got);
+                    off = __builtin_amdgcn_readfirstlane(off + got);
+                    if (off >= 64u) {   // batch cb is used up: its quarter of the ring takes batch cb + 4
+                        off -= 64u;
+                        cb = __builtin_amdgcn_readfirstlane(cb + 1u);
+                        ring[(((cb + 3u) & 3u) << 6) + lane] = pick_batch(B, cb + 3u);
+                    }
+                }
+                if (DIAG) ++d_rounds;
+                probe();
+            }
+            // ---- the stream is dry: the batch registers take the next segment's first batches
+            if (pass + 1u == npass && look_ahead < 4) {
+                nx_seg = 0xFFFFFFFFu;
+                if (seg2 < nseg) {
+                    nx_n = seg_total(sizes2);
+                    nx_seg = seg2;
+                    if (nx_n) {
+                        nx_mine = my_list(seg2, sizes2, nx_base);
+                        load_batches(nx_base, nx_mine, wi, nw, 0, lane, B);
+                    }
+                }
+            }
+            // ---- the tail.  The wave works on its last keys only, and they meet the segment at its final load: the
+            // longest of the ~2000 probe chains in flight is ~25 probes, ~16 rounds of a wave's ~38 run with a handful
+            // of lanes.  A lane that is still probing looks at its next three probe positions as well (plain reads,
+            // issued together) and steps over those that hold ANOTHER key: slots never become empty again, so a slot
+            // seen taken by someone else stays out of the question; a slot seen empty or holding this key is where the
+            // next round's CAS goes.  (Seven positions instead of three: no better, 6.04 vs 5.97 ms; looking ahead in
+            // every round, not only in the tail: worse, 6.73 ms -- the main phase is bound by instruction issue.)
+            while (__ballot(i != 0u) != 0ULL) {
+                if (DIAG) ++d_rounds;
+                probe();
+                if (look_ahead && i != 0u && i + 3u < maxr) {
+                    const uint32_t q1 = (q + i + 1u) & smask, q2 = (q1 + i + 2u) & smask, q3 = (q2 + i + 3u) & smask;
+                    const uint64_t v0 = s_seg[q], v1 = s_seg[q1], v2 = s_seg[q2];
+                    const bool t0 = v0 != 0 && (v0 & k0mask) != (e0 | i);
+                    const bool t1 = t0 && v1 != 0 && (v1 & k0mask) != (e0 | (i + 1u));
+                    const bool t2 = t1 && v2 != 0 && (v2 & k0mask) != (e0 | (i + 2u));
+                    if (t2) { i += 3u; q = q3; }
+                    else if (t1) { i += 2u; q = q2; }
+                    else if (t0) { i += 1u; q = q1; }
                 }
             }
             if (DIAG && (dbg & 16) && lane == 0) {

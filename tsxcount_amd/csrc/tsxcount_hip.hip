@@ -736,7 +736,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     const int rw = pl.rw;
     // ring depth in words: PART_FLUSH-1 words may stay behind a flush, plus one batch of arrivals (mean = batch / nb)
     auto ring_bits = [](uint32_t nb) {
-        const uint32_t mean = std::max<uint32_t>(1, PART_NT * PART_WPT / nb);
+        const uint32_t mean = std::max<uint32_t>(1, RING_NT * PART_WPT / nb);
         uint32_t bits = 4;
         while ((1u << bits) < PART_FLUSH + 2 * mean && bits < 6) ++bits;
         if (const char *e = getenv("TSX_HIP_RING_BITS")) bits = (uint32_t)std::min(6, std::max(4, atoi(e)));   // experiments
@@ -748,7 +748,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, pl.nb1, pl.c_bstart, pl.c_bcnt);
     {   // level 1: every region -> packed array ordered by the top b1 bits of the home slot
         const uint32_t bits = ring_bits(pl.nb1);
-        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.g), dim3(PART_NT), part_lds(pl.nb1, bits), st,
+        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.g), dim3(RING_NT), part_lds(pl.nb1, bits), st,
                            pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,
                            m->d_buf[1], (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
@@ -773,7 +773,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
             HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, (size_t)nq2 * 4));
             m->ovq_queues = (size_t)nq2 * rw;
         }
-        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(PART_NT),
+        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(RING_NT),
                            part_lds(pl.nb2, bits), st, pp, (const uint64_t *)m->d_buf[1],
                            (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
                            pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
@@ -924,9 +924,15 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     // scan -> key log + histogram by level-1 bucket, or by owner GPU for a sharded scan
     const uint32_t hist_nb = shard_send ? nown : pl.nb1, hist_shift = (uint32_t)(shard_send ? p.l : p.l - pl.b1);
     if (p.wk == 1) {
-        hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
-                           (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
-                           hist_nb, hist_shift);
+        static const int scan_v = getenv("TSX_HIP_SCAN_V") ? atoi(getenv("TSX_HIP_SCAN_V")) : 2;   // 1: strips walked in place
+        if (scan_v == 1)
+            hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
+                               (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
+                               hist_nb, hist_shift);
+        else
+            hipLaunchKernelGGL(scan_queue_kernel, dim3(gs), dim3(NT), lut_bytes + (NT / 64) * hist_nb * 4, st, pp, d_text, n,
+                               own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
+                               pl.c_log, pl.d_hist, hist_nb, hist_shift);
     } else {
         switch (p.wk) {
             case 2: hipLaunchKernelGGL((scan_log_wide_kernel<2>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
