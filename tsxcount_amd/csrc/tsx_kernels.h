@@ -74,12 +74,23 @@ __device__ __forceinline__ bool prev_is_nl(const uint8_t *buf, uint64_t off, uin
     return buf[off - 1] == (uint8_t)'\n';
 }
 
-template <typename T>
-__device__ __forceinline__ T wave_incl_scan(T v) {
+// Inclusive prefix sum over the wave in six DPP adds (rows of 16 by row_shr 1/2/4/8, then lane 15 of a row
+// into the next row and lane 31 into the upper half); the shuffle form went through the LDS pipe six times.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long long v) {   // small kernels only
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        T o = __shfl_up(v, d, 64);
+        const unsigned long long o = __shfl_up(v, d, 64);
         if (lane >= d) v += o;
     }
     return v;
@@ -388,20 +399,28 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
         defer_append1(pk, hkey, d);
     };
 
+    // the tile's 16 bytes of this lane and "the byte before them is a newline" are loaded one tile ahead (the
+    // first version waited for two dependent loads at the top of every tile)
+    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
+    bool cur_pnl = true;
+    if ((uint64_t)blockIdx.x < ntiles) {
+        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
+        cur = load16(buf, off, n);
+        cur_pnl = prev_is_nl(buf, off, n, head_open);
+        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
+    }
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
         lds_barrier();  // previous tile's LDS fully consumed
         {
-            const uint64_t off = base + (uint64_t)tid * 16;
             uint32_t nl, le, code;
-            classify16(load16(buf, off, n), prev_is_nl(buf, off, n, head_open), nl, le, code);
+            classify16(cur, cur_pnl, nl, le, code);
             reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
             reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
             reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
             if (tid < HALO / 16) {
-                const uint64_t hoff = base + TILE + (uint64_t)tid * 16;
                 uint32_t hnl, hle, hcode;
-                classify16(load16(buf, hoff, n), false, hnl, hle, hcode);
+                classify16(hcur, false, hnl, hle, hcode);
                 reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
                 reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
             }
@@ -412,6 +431,15 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
             uint32_t woff = tile_line[tile];
             for (int w = 0; w < wave; ++w) woff += s_wsum[w];
             s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        {
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
+                cur = load16(buf, off, n);
+                cur_pnl = prev_is_nl(buf, off, n, head_open);
+                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
+            }
         }
         lds_barrier();
 
@@ -578,303 +606,6 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
                 }
             }
         }
-    }
-    lds_barrier();
-    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
-    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
-    if (lane == 0) {
-        if (added) atomicAdd(&p.stats[ST_KMERS], added);
-        log_cnt[region] = min(fill, cap32);
-    }
-    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
-}
-
-// scan_log_kernel with the strips COMPACTED before they are walked.  Lines of a read file are about as long
-// as a wave's share of a tile (1 KiB), so nearly every wave of scan_log_kernel holds some sequence bytes and
-// walks its 16 positions with half of its lanes idle (the other half sit in '+'/quality lines): the roll and
-// append instructions, two thirds of the kernel, ran at 50 % lane use.  Here a lane only DESCRIBES its strip
-// (the 48 bases from its first position + the 16 validity bits = 16 bytes) and pushes the description to a
-// workgroup queue in LDS if any position is valid; waves then take whole batches of 64 descriptions and walk
-// them with every lane busy.  What is left (< 64) moves to the front of the queue and waits for the next tile.
-// The next tile's text is loaded before the walk (the old kernel waited for two dependent loads per tile).
-// Log regions, histogram, hot cache and deferred list: as in scan_log_kernel.
-constexpr int SQ_CAP = 320;   // 63 descriptions left over + one per lane
-__global__ __launch_bounds__(NT, 5) void scan_queue_kernel(TableParams p, const uint8_t *buf, uint64_t n,
-                                                           uint64_t own_end, int head_open, const uint32_t *tile_line,
-                                                           uint64_t ntiles, int dbg, uint64_t *log, uint64_t log_cap,
-                                                           unsigned long long *log_cnt, uint32_t *hist, uint32_t hist_nb,
-                                                           uint32_t hist_shift) {
-    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
-    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
-    __shared__ uint64_t s_le[TILE / 64];
-    __shared__ uint8_t s_lb[TILE / 16];
-    __shared__ uint32_t s_wsum[NT / 64];
-    constexpr int HOT_N = 8;
-    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
-    __shared__ uint64_t s_roll[64];
-    __shared__ uint64_t s_homh[4];     // hashes of the four homopolymer k-mers
-    __shared__ uint4 s_q[SQ_CAP];      // strip descriptions: {codes of bases 0-15, 16-31, 32-47, validity bits}
-    __shared__ uint32_t s_qn;          // descriptions in the queue
-    extern __shared__ uint64_t s_lut[];   // LUT, then one histogram of hist_nb counters per wave
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lut_words = p.groups * (1 << p.g);
-    uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_lut + lut_words);
-    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
-    for (uint32_t i = tid; i < (NT / 64) * hist_nb; i += NT) s_hist[i] = 0;
-    if (tid < 64) s_roll[tid] = p.roll[tid];
-    if (tid < 4) {   // straight from the global LUT: s_lut is not complete before the first barrier
-        const uint64_t x[1] = {(0x5555555555555555ULL * (uint64_t)tid) & p.top_mask};
-        uint64_t hh[1];
-        hash_apply<1>(p, p.lut, x, hh);
-        s_homh[tid] = hh[0];
-    }
-    if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
-    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
-    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
-    unsigned long long added = 0;
-    const uint32_t k = (uint32_t)p.k;
-    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
-    uint64_t *my_log = log + (uint64_t)region * log_cap;
-    uint32_t *my_hist = s_hist + wave * hist_nb;
-    uint32_t fill = 0;  // wave-uniform
-    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
-    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
-    const uint64_t lt = (1ULL << lane) - 1ULL;
-
-    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    auto side_insert = [&](uint64_t hkey, uint64_t d) {
-        if (dbg & 1) return;
-        defer_append1(pk, hkey, d);
-    };
-
-    // Walks one description per lane (vm == 0: the lane has none): first window by LUT, 15 rolls, keys to the
-    // wave's log region.  Identical to the strip part of scan_log_kernel, fed from registers.
-    auto walk = [&](const uint32_t cw0, const uint32_t cw1, const uint32_t cw2, const uint32_t vm) {
-        const uint64_t lo = (uint64_t)cw0 | ((uint64_t)cw1 << 32), hi = cw2;
-        uint64_t h = 0;
-        if (vm) {
-            const uint64_t x[1] = {lo & p.top_mask};
-            uint64_t hh[1];
-            hash_apply<1>(p, (const uint64_t *)s_lut, x, hh);
-            h = hh[0];
-        }
-        uint32_t inc;   // bases entering the window: codes from base k on
-        {
-            const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
-            const uint32_t w0 = (ws == 0u) ? cw0 : (ws == 1u) ? cw1 : cw2;
-            const uint32_t w1 = (ws == 0u) ? cw1 : (ws == 1u) ? cw2 : 0u;
-            inc = __funnelshift_r(w0, w1, sh);
-        }
-        uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
-        {
-            const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
-            uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
-            uint32_t span = 1;
-            while (span * 2 <= k - 1) {
-                const uint32_t sh = 2u * span;
-                rlo |= (rlo >> sh) | (rhi << (64u - sh));
-                rhi |= rhi >> sh;
-                span *= 2;
-            }
-            if (span < k - 1) {
-                const uint32_t sh = 2u * (k - 1 - span);
-                rlo |= (rlo >> sh) | (rhi << (64u - sh));
-            }
-            uint32_t x = ~(uint32_t)rlo & 0x55555555u;
-            x = (x | (x >> 1)) & 0x33333333u;
-            x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-            x = (x | (x >> 4)) & 0x00FF00FFu;
-            homm = (x | (x >> 8)) & 0xFFFFu;
-        }
-        const uint32_t hv = vm & homm;
-        const uint32_t single = vm & ~homm;
-        if (__ballot(hv != 0u)) {
-            for (uint32_t b = 0; b < 4; ++b) {
-                uint32_t e = cw0 ^ (0x55555555u * b);
-                uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
-                y = (y | (y >> 1)) & 0x33333333u;
-                y = (y | (y >> 2)) & 0x0F0F0F0Fu;
-                y = (y | (y >> 4)) & 0x00FF00FFu;
-                y = (y | (y >> 8)) & 0xFFFFu;
-                uint32_t tot = (uint32_t)__popc(hv & y);
-                if (__ballot(tot != 0u) == 0ULL) continue;
-                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                if (lane == 0) {
-                    const uint64_t key = s_homh[b];
-                    uint64_t *hkey = s_hot_key + wave * HOT_N;
-                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
-                    int at = -1;
-                    for (int q = 0; q < HOT_N; ++q)
-                        if (hcnt[q] && hkey[q] == key) { at = q; break; }
-                    if (at < 0)
-                        for (int q = 0; q < HOT_N; ++q)
-                            if (!hcnt[q]) { at = q; hkey[q] = key; break; }
-                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
-                    else side_insert(key, tot);
-                }
-            }
-        }
-        for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
-            const uint32_t s8 = (single >> j0) & 0xFFu;
-            if (__ballot(s8 != 0u) == 0ULL) {   // nothing to log in this half: only roll on
-                if (j0 == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
-                                             (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
-                        h = (h >> 2) ^ s_roll[idx];
-                    }
-                }
-                continue;
-            }
-            uint64_t hs[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hs[j] = h;
-                if (j0 + j < 15) {
-                    const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
-                                         (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
-                    h = (h >> 2) ^ s_roll[idx];
-                }
-            }
-            if (fill + 64u * 8u <= cap32) {   // the usual case: the region has room for whatever this half logs
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool em = (s8 >> j) & 1u;
-                    const unsigned long long mk = __ballot(em);
-                    if (mk) {
-                        if (em) {
-                            const uint64_t key = hs[j];
-                            my_log[fill + (uint32_t)__builtin_popcountll(mk & lt)] = key;
-                            atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
-                        }
-                        fill += (uint32_t)__builtin_popcountll(mk);
-                    }
-                }
-            } else {
-                for (int j = 0; j < 8; ++j) {
-                    const bool em = (s8 >> j) & 1u;
-                    const unsigned long long mk = __ballot(em);
-                    if (mk) {
-                        if (em) {
-                            uint64_t key = hs[0];
-#pragma unroll
-                            for (int t = 1; t < 8; ++t) key = (j == t) ? hs[t] : key;
-                            const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & lt);
-                            if (at < cap32) {
-                                my_log[at] = key;
-                                atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
-                            } else {
-                                side_insert(key, 1);  // region full: deferred list (or the exchanged hot list)
-                            }
-                        }
-                        fill += (uint32_t)__builtin_popcountll(mk);
-                    }
-                }
-            }
-        }
-    };
-
-    uint32_t left = 0;   // descriptions waiting in the queue (workgroup-uniform)
-    uint32_t iter = 0;
-    // the tile's 16 bytes of this lane and "the byte before them is a newline", loaded one tile ahead
-    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
-    bool cur_pnl = true;
-    if ((uint64_t)blockIdx.x < ntiles) {
-        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
-        cur = load16(buf, off, n);
-        cur_pnl = prev_is_nl(buf, off, n, head_open);
-        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
-    }
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
-        const uint64_t base = tile * TILE;
-        lds_barrier();  // previous tile's LDS fully consumed
-        if (tid == 0) s_qn = left;
-        {
-            uint32_t nl, le, code;
-            classify16(cur, cur_pnl, nl, le, code);
-            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
-            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
-            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
-            if (tid < HALO / 16) {
-                uint32_t hnl, hle, hcode;
-                classify16(hcur, false, hnl, hle, hcode);
-                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
-                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
-            }
-            const uint32_t c = __popc(le);
-            const uint32_t inc = wave_incl_scan(c);
-            if (lane == 63) s_wsum[wave] = inc;
-            lds_barrier();
-            uint32_t woff = tile_line[tile];
-            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
-            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
-        }
-        {   // next tile's text: in flight during the rest of this tile
-            const uint64_t nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
-                cur = load16(buf, off, n);
-                cur_pnl = prev_is_nl(buf, off, n, head_open);
-                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
-            }
-        }
-        lds_barrier();
-
-        // ---- describe this lane's strip: start positions s .. s+15 of the tile -----------
-        {
-            const uint32_t s0 = (uint32_t)tid * 16;
-            const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
-            const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
-            uint64_t m;   // newline flags of bytes [s, s+64)
-            {
-                const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
-                const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2];
-                m = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
-            }
-            uint64_t r = m;   // bad_j = a newline in [s+j, s+j+k)
-            uint32_t span = 1;
-            while (span * 2 <= k) { r |= r >> span; span *= 2; }
-            if (span < k) r |= r >> (k - span);
-            const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
-            const uint32_t lb = s_lb[tid];
-            uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
-            uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
-            const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
-            const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
-            const uint64_t g0 = base + s0;
-            const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
-            const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;   // FASTA: every second line is a sequence
-            const uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);
-            added += (unsigned long long)__popc(vm);
-            const unsigned long long hb = __ballot(vm != 0u);
-            if (hb) {
-                uint32_t qb = 0;
-                if (lane == 0) qb = atomicAdd(&s_qn, (uint32_t)__builtin_popcountll(hb));
-                qb = __builtin_amdgcn_readfirstlane(qb);
-                if (vm) s_q[qb + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm);
-            }
-        }
-        lds_barrier();
-        // ---- walk whole batches of 64 descriptions; the waves take turns so that every SIMD gets its share ----
-        // (the workgroup's last tile also walks the batch that is not full)
-        const bool last = tile + gridDim.x >= ntiles;
-        const uint32_t total = s_qn, nfull = total >> 6, nbat = last ? (total + 63u) >> 6 : nfull;
-        for (uint32_t b = ((uint32_t)wave + 4u - (iter & 3u)) & 3u; b < nbat; b += NT / 64) {
-            const uint32_t qi = b * 64u + (uint32_t)lane;
-            uint4 d = s_q[qi];
-            if (qi >= total) d.w = 0u;
-            if (b == 0u && !last) {   // the wave that holds batch 0 in registers moves the remainder to the front
-                const uint32_t rem = total & 63u;
-                uint4 mv = make_uint4(0, 0, 0, 0);
-                if ((uint32_t)lane < rem) mv = s_q[nfull * 64u + (uint32_t)lane];
-                if ((uint32_t)lane < rem) s_q[lane] = mv;
-            }
-            walk(d.x, d.y, d.z, d.w);
-        }
-        left = nfull ? (total & 63u) : total;
     }
     lds_barrier();
     if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void offsets_rows_kernel(const uint32_t *hist
     for (uint32_t start = 0; start < G; start += 1024) {
         const uint32_t i = start + tid;
         const unsigned long long v = (i < G) ? hist[(size_t)b * G + i] : 0;
-        const unsigned long long inc = wave_incl_scan(v);
+        const unsigned long long inc = wave_incl_scan64(v);
         if ((tid & 63) == 63) s_w[tid >> 6] = inc;
         __syncthreads();
         unsigned long long woff = 0;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(1024) void offsets_finish_kernel(uint32_t nb, unsig
     __shared__ unsigned long long s_w[16];
     const uint32_t tid = threadIdx.x;
     const unsigned long long v = (tid < nb) ? bucket_cnt[tid] : 0;
-    const unsigned long long inc = wave_incl_scan(v);
+    const unsigned long long inc = wave_incl_scan64(v);
     if ((tid & 63) == 63) s_w[tid >> 6] = inc;
     __syncthreads();
     unsigned long long woff = 0;

@@ -924,15 +924,9 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     // scan -> key log + histogram by level-1 bucket, or by owner GPU for a sharded scan
     const uint32_t hist_nb = shard_send ? nown : pl.nb1, hist_shift = (uint32_t)(shard_send ? p.l : p.l - pl.b1);
     if (p.wk == 1) {
-        static const int scan_v = getenv("TSX_HIP_SCAN_V") ? atoi(getenv("TSX_HIP_SCAN_V")) : 2;   // 1: strips walked in place
-        if (scan_v == 1)
-            hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
-                               (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
-                               hist_nb, hist_shift);
-        else
-            hipLaunchKernelGGL(scan_queue_kernel, dim3(gs), dim3(NT), lut_bytes + (NT / 64) * hist_nb * 4, st, pp, d_text, n,
-                               own_end, head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
-                               pl.c_log, pl.d_hist, hist_nb, hist_shift);
+        hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
+                           (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
+                           hist_nb, hist_shift);
     } else {
         switch (p.wk) {
             case 2: hipLaunchKernelGGL((scan_log_wide_kernel<2>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
