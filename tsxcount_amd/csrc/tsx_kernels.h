@@ -688,20 +688,27 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
     const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
     const uint64_t lt = (1ULL << lane) - 1ULL;
 
+    // text loaded one tile ahead, as in scan_log_kernel
+    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
+    bool cur_pnl = true;
+    if ((uint64_t)blockIdx.x < ntiles) {
+        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
+        cur = load16(buf, off, n);
+        cur_pnl = prev_is_nl(buf, off, n, head_open);
+        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
+    }
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * TILE;
         lds_barrier();  // previous tile's LDS fully consumed
         {
-            const uint64_t off = base + (uint64_t)tid * 16;
             uint32_t nl, le, code;
-            classify16(load16(buf, off, n), prev_is_nl(buf, off, n, head_open), nl, le, code);
+            classify16(cur, cur_pnl, nl, le, code);
             reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
             reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
             reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
             if (tid < HALO / 16) {
-                const uint64_t hoff = base + TILE + (uint64_t)tid * 16;
                 uint32_t hnl, hle, hcode;
-                classify16(load16(buf, hoff, n), false, hnl, hle, hcode);
+                classify16(hcur, false, hnl, hle, hcode);
                 reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
                 reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
             }
@@ -712,6 +719,15 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
             uint32_t woff = tile_line[tile];
             for (int w = 0; w < wave; ++w) woff += s_wsum[w];
             s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        {
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
+                cur = load16(buf, off, n);
+                cur_pnl = prev_is_nl(buf, off, n, head_open);
+                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
+            }
         }
         lds_barrier();
 

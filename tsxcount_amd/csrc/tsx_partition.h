@@ -1104,21 +1104,41 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
     const uint32_t maxr = p.max_reprobes;
     const uint64_t one = 1ULL << p.cshift;
 
-    auto my_list = [&](uint32_t seg, const uint64_t *&base) -> uint32_t {
-        if (list_start) { base = lists + (uint64_t)list_start[seg] * RW; return (uint32_t)list_cnt[seg]; }
-        base = lists + ((uint64_t)seg * pieces + grp) * list_cap * RW;
-        return (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + grp], list_cap);
+    // list sizes of a segment in one load per wave (lane c: piece c), as in build_segments_stream_kernel
+    auto list_sizes = [&](uint32_t seg) -> uint32_t {
+        if (list_start) return lane == 0u ? (uint32_t)list_cnt[seg] : 0u;
+        return lane < pieces ? (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + lane], list_cap) : 0u;
     };
-    auto seg_keys = [&](uint32_t seg) -> uint64_t {
-        if (list_start) return (uint64_t)list_cnt[seg];
-        uint64_t n = 0;
-        for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
-        return n;
+    auto seg_total = [&](uint32_t c) -> uint32_t {
+        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+        return __builtin_amdgcn_readfirstlane(c);
+    };
+    auto my_list = [&](uint32_t seg, uint32_t c, const uint64_t *&base) -> uint32_t {
+        if (list_start) { base = lists + (uint64_t)list_start[seg] * RW; return __builtin_amdgcn_readfirstlane(c); }
+        base = lists + ((uint64_t)seg * pieces + grp) * list_cap * RW;
+        return __builtin_amdgcn_readlane(c, grp);
     };
 
     uint64_t B[BKW][RW];
+    auto load_pass = [&](const uint64_t *base, uint32_t mine, uint32_t pass) {
+#pragma unroll
+        for (int j = 0; j < BKW; ++j) {
+            const uint32_t idx = (wi + (pass * BKW + (uint32_t)j) * nw) * 64u + lane;
+            if (idx < mine) load_rec<RW>(base + (uint64_t)idx * RW, B[j]);
+            else {
+#pragma unroll
+                for (int t = 0; t < RW; ++t) B[j][t] = 0;
+            }
+        }
+    };
+    // the next segment's first batches are loaded when the last batch of this one has been staged (B is free then)
+    uint32_t nx_seg = 0xFFFFFFFFu, nx_mine = 0, nx_n = 0;
+    const uint64_t *nx_base = nullptr;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        const uint64_t n = seg_keys(seg);
+        const bool have = (nx_seg == seg);
+        uint32_t sizes = 0;
+        if (!have) sizes = list_sizes(seg);
+        const uint64_t n = have ? nx_n : seg_total(sizes);
         uint64_t *slots = p.table + ((uint64_t)seg << p.S) * W;
         if (n == 0) {
             if (fresh) {
@@ -1129,20 +1149,15 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
             continue;
         }
         const bool dirty = !fresh && p.seg_dirty[seg] != 0;
-        const uint64_t *base;
-        const uint32_t mine = my_list(seg, base);
-        auto load_pass = [&](uint32_t pass) {
-#pragma unroll
-            for (int j = 0; j < BKW; ++j) {
-                const uint32_t idx = (wi + (pass * BKW + (uint32_t)j) * nw) * 64u + lane;
-                if (idx < mine) load_rec<RW>(base + (uint64_t)idx * RW, B[j]);
-                else {
-#pragma unroll
-                    for (int t = 0; t < RW; ++t) B[j][t] = 0;
-                }
-            }
-        };
-        load_pass(0);
+        const uint64_t *base = nx_base;
+        uint32_t mine = nx_mine;
+        if (!have) {
+            mine = my_list(seg, sizes, base);
+            load_pass(base, mine, 0);
+        }
+        const uint32_t seg2 = seg + gridDim.x;
+        uint32_t sizes2 = 0;
+        if (seg2 < nseg) sizes2 = list_sizes(seg2);
         lds_barrier();  // previous segment fully written out
         if (dirty) {
             for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
@@ -1154,7 +1169,7 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
         lds_barrier();
         const uint32_t npass = ((mine + 63u) / 64u + nw * BKW - 1u) / (nw * BKW);
         for (uint32_t pass = 0; pass < npass; ++pass) {
-            if (pass > 0) load_pass(pass);
+            if (pass > 0) load_pass(base, mine, pass);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // the batches have arrived: the one wait for loads of this pass
             uint32_t cb = 0;        // batch of the pass that sits in the ring
             uint32_t blen = 0;      // its length
@@ -1176,7 +1191,19 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
                 }
                 return len;
             };
+            auto take_next = [&]() {   // B takes the next segment's first batches
+                nx_seg = 0xFFFFFFFFu;
+                if (seg2 < nseg) {
+                    nx_n = seg_total(sizes2);
+                    nx_seg = seg2;
+                    if (nx_n) {
+                        nx_mine = my_list(seg2, sizes2, nx_base);
+                        load_pass(nx_base, nx_mine, 0);
+                    }
+                }
+            };
             blen = stage(0);
+            if (blen == 0 && pass + 1u == npass) take_next();
             uint64_t e0 = 0, hi[4] = {0, 0, 0, 0};
             uint32_t i = 0, q = 0, spins = 0;   // i == 0: the lane holds no key
             for (;;) {
@@ -1204,6 +1231,7 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
                     cb = __builtin_amdgcn_readfirstlane(cb + 1u);
                     off = 0;
                     blen = stage(cb);
+                    if (blen == 0 && pass + 1u == npass) take_next();   // that was the last one: B is free
                 }
                 if (__ballot(i != 0u) == 0ULL) {
                     if (blen == 0) break;   // stream dry and every key placed
