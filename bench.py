@@ -281,7 +281,9 @@ def main():
         # (DESIGN.md section 3).  Reported for the dominant kernel (the scan kernel, which in
         # the partitioned path reads the text and writes one 8-byte key per logged k-mer) and
         # for the whole device path of a step.
-        pieces = max(launches, 1)
+        # stage times are sums over the timed calls: one call per step, or (sharded table) one scan call per window
+        # plus one build call per step -- per-step figures either way
+        pieces = args.steps if sharded else max(launches, 1)
         partitioned = build_ms / pieces > 0.5
         keys_logged = st["distinct"] if partitioned else 0
         # algorithmic bytes of each stage of one launch: the scan kernel reads the
