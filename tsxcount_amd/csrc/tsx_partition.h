@@ -78,13 +78,15 @@ __device__ __forceinline__ void store_rec(uint64_t *ptr, const uint64_t (&r)[RW]
 constexpr uint32_t OVF_N = 64;
 constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
 
+constexpr int PART_MAX_PIECES = 512;   // pieces of a source region one workgroup may have to walk (src_np / cpr)
 constexpr int PART_ITER = 4;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
 template <int RW>
 __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
-    uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap) {
+    uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap,
+    const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap) {
     constexpr int RPT = (PART_WPT >= RW) ? PART_WPT / RW : 1;   // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
@@ -113,9 +115,13 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap * RW; s_lim[b] = s_cur[b] + dst_cap * RW; }
     }
     lds_barrier();
-    const uint64_t n = src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap);   // records
-    const uint64_t *in = src + (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap) * RW;
-    constexpr uint64_t BATCH_REC = (uint64_t)RING_NT * RPT;
+    // The source region r: a contiguous run of records (src_start/src_cnt, or src_cap apart), or -- src_pcnt
+    // given -- src_np PIECES of at most src_pcap records each, piece g at ((r * src_np + g) * src_pcap) with
+    // src_pcnt[r * src_np + g] records (the sub-lists scan_part_kernel's workgroups keep per level-1 bucket);
+    // workgroup c of the region then takes pieces c, c + cpr, ... as one stream.
+    const uint64_t n = src_pcnt ? 0 : (src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap));   // records
+    const uint64_t region_first = src_pcnt ? 0 : (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
+    constexpr uint32_t BATCH_REC = (uint32_t)RING_NT * RPT;
     const uint64_t stride = (uint64_t)cpr * BATCH_REC;
 
     // TableParams is the first kernel argument: the slow paths read it from the argument segment
@@ -230,47 +236,86 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         }
     };
 
-    uint64_t cur[RPT][RW], nxt[RPT][RW];
-    uint64_t base = (uint64_t)c * BATCH_REC;
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const uint64_t i = base + (uint64_t)q * RING_NT + tid;
-        if (i < n) load_rec<RW>(in + i * RW, cur[q]);
-        else {
-#pragma unroll
-            for (int t = 0; t < RW; ++t) cur[q][t] = 0;
-        }
+    // A batch: record j (j = q * RING_NT + tid) comes from record index first + j, or first + j + delta once
+    // j >= rem (a batch may run from the end of one piece into the next one); nvalid records in all.
+    struct Batch { uint64_t first, delta; uint32_t rem, nvalid; };
+    uint64_t base = (uint64_t)c * BATCH_REC;   // contiguous source: next batch
+    uint32_t poff = 0;                         // pieces: records consumed of the current piece
+    // the sizes of this workgroup's pieces (c, c + cpr, ...) wait in LDS: the stream logic below is on the
+    // critical path of every batch and must not go to memory
+    __shared__ uint32_t s_pc[PART_MAX_PIECES];
+    if (src_pcnt) {
+        for (uint32_t i = tid; c + i * cpr < src_np && i < (uint32_t)PART_MAX_PIECES; i += RING_NT)
+            s_pc[i] = (uint32_t)min((uint64_t)src_pcnt[(uint64_t)r * src_np + c + i * cpr], src_pcap);
+        lds_barrier();
     }
+    const uint32_t npw = (src_pcnt && c < src_np) ? min((src_np - c + cpr - 1) / cpr, (uint32_t)PART_MAX_PIECES) : 0u;
+    uint32_t pi = 0;   // ordinal of the current piece: piece c + pi * cpr of the region
+    auto pcnt = [&](uint32_t i) -> uint32_t { return i < npw ? s_pc[i] : 0u; };
+    auto next_batch = [&]() -> Batch {   // workgroup-uniform; describes the next batch and moves on
+        Batch d;
+        d.delta = 0;
+        if (!src_pcnt) {
+            d.first = region_first + base;
+            d.rem = BATCH_REC;
+            d.nvalid = base < n ? (uint32_t)min((uint64_t)BATCH_REC, n - base) : 0u;
+            base += stride;
+            return d;
+        }
+        while (pi < npw) {   // pieces that are used up (or empty)
+            const uint32_t cg = pcnt(pi);
+            if (poff < cg) break;
+            poff -= cg;
+            ++pi;
+        }
+        if (pi >= npw) { d.first = 0; d.rem = 0; d.nvalid = 0; return d; }
+        const uint32_t left = pcnt(pi) - poff, cb = pcnt(pi + 1);
+        const uint64_t pa = (uint64_t)r * src_np + c + (uint64_t)pi * cpr;   // number of the piece among all
+        d.first = pa * src_pcap + poff;
+        d.rem = min(left, BATCH_REC);
+        d.delta = (pa + cpr) * src_pcap - (d.first + left);
+        d.nvalid = (uint32_t)min((uint64_t)BATCH_REC, (uint64_t)left + cb);
+        if (left > BATCH_REC) poff += BATCH_REC;
+        else { ++pi; poff = d.nvalid - left; }
+        return d;
+    };
+    auto load_batch = [&](const Batch &d, uint64_t (&regs)[RPT][RW]) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t j = (uint32_t)q * RING_NT + tid;
+            if (j < d.nvalid) load_rec<RW>(src + (d.first + j + (j >= d.rem ? d.delta : 0ULL)) * RW, regs[q]);
+            else {
+#pragma unroll
+                for (int t = 0; t < RW; ++t) regs[q][t] = 0;
+            }
+        }
+    };
+    uint64_t cur[RPT][RW], nxt[RPT][RW];
+    Batch bc = next_batch();
+    load_batch(bc, cur);
     // The first batch must have ARRIVED before the loop: the compiler then knows that `cur` is complete at the
     // loop header on both edges and waits for the next batch's loads where they are consumed (the copies at the
     // end of the batch) -- not right behind their issue, which is what it did without this wait: vmcnt(0) in
     // front of the first use of `cur`, i.e. one full HBM latency per batch and no prefetch at all.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-    for (; base < n; base += stride) {
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const uint64_t i = base + stride + (uint64_t)q * RING_NT + tid;
-            if (i < n) load_rec<RW>(in + i * RW, nxt[q]);
-            else {
-#pragma unroll
-                for (int t = 0; t < RW; ++t) nxt[q][t] = 0;
-            }
-        }
+    while (bc.nvalid) {
+        const Batch bn = next_batch();
+        load_batch(bn, nxt);
         // all ring places of the batch are taken before any is used: the returning LDS atomics
         // of a thread are in flight together
         uint32_t bq[RPT], slot[RPT], head[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * RING_NT + tid;
+            const uint32_t j = (uint32_t)q * RING_NT + tid;
             bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
-            slot[q] = (i < n) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
+            slot[q] = (j < bc.nvalid) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) head[q] = s_head[bq[q]];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint64_t i = base + (uint64_t)q * RING_NT + tid;
-            if (i < n) {
+            const uint32_t j = (uint32_t)q * RING_NT + tid;
+            if (j < bc.nvalid) {
                 const uint32_t b = bq[q];
                 if (slot[q] - head[q] < CAP) {   // RW | CAP and records are RW-aligned: a record never wraps
                     uint64_t *ring = s_stage + ((size_t)b << capbits) + (slot[q] & cmask);
@@ -290,6 +335,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         for (int q = 0; q < RPT; ++q)
 #pragma unroll
             for (int t = 0; t < RW; ++t) cur[q][t] = nxt[q][t];
+        bc = bn;
     }
     flush(true);
     lds_barrier();
@@ -308,6 +354,362 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
     for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
     if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
+}
+
+// ---- scan fused with radix level 1 (one-limb keys, two-level split) -----------------------------------------
+// scan_log_kernel writes every key to a log that level 1 reads again: 12.9 GB and a 3 ms launch per 1e9 k-mers
+// for nothing but a histogram.  This kernel keeps the level-1 staging rings next to the scan: the keys of a
+// strip go straight into the ring of their level-1 bucket, bursts of 128 B leave for the workgroup's own
+// sub-list of that bucket (fixed capacity dst_cap, list (b, g) at ((b * G + g) * dst_cap), its size in
+// dst_cnt[b * G + g]; what does not fit: spill cache / overflow queue / deferred list, exactly as in level 2).
+// Level 2 reads a bucket as the G pieces the workgroups left (partition_ring_kernel, src_pcnt).
+// 512 threads, 8 KiB of text per tile, two workgroups per CU: the rings take 64 KiB, the LUT of the first
+// window is the 4-bit-group one (2 KiB, 16 lookups per strip instead of 8) so that two workgroups fit.
+// A tile: classify -> line index -> strip masks, first window -> [8 rolls, append to rings, flush] x 2.
+constexpr int SP_NT = 512;
+constexpr int SP_TILE = SP_NT * 16;
+constexpr uint32_t SP_CAPBITS = 5;   // 32 words per ring: 15 may stay behind a flush, ~7 arrive per half strip
+
+__global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
+                                                            int head_open, const uint32_t *tile_line, uint64_t ntiles,
+                                                            int dbg, uint64_t *dst, uint64_t dst_cap,
+                                                            unsigned long long *dst_cnt, uint32_t nb, uint32_t shift,
+                                                            uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap) {
+    __shared__ uint64_t s_codes[(SP_TILE + HALO) / 32 + 2];
+    __shared__ uint64_t s_nl[(SP_TILE + HALO) / 64 + 3];
+    __shared__ uint64_t s_le[SP_TILE / 64];
+    __shared__ uint8_t s_lb[SP_TILE / 16];
+    __shared__ uint32_t s_wsum[SP_NT / 64];
+    constexpr int HOT_N = 8;
+    __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
+    __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
+    __shared__ uint64_t s_roll[64];
+    __shared__ uint64_t s_lut4[256];
+    __shared__ uint64_t s_homh[4];
+    __shared__ uint32_t s_njobs[2];
+    __shared__ uint32_t s_ovn;
+    __shared__ uint64_t s_ovk[OVF_N];
+    __shared__ uint32_t s_ovc[OVF_N];
+    extern __shared__ uint64_t s_part[];   // rings | flush descriptors | cursors | tails | heads | jobs
+    constexpr uint32_t CAP = 1u << SP_CAPBITS, cmask = CAP - 1;
+    uint64_t *s_stage = s_part;
+    unsigned long long *s_meta = reinterpret_cast<unsigned long long *>(s_part + ((size_t)nb << SP_CAPBITS));
+    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_meta + nb);   // words written to the own sub-list of the bucket
+    uint32_t *s_tail = s_cur + nb;
+    uint32_t *s_head = s_tail + nb;
+    uint32_t *s_job = s_head + nb;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = gridDim.x, wg = blockIdx.x;
+    const uint32_t cap32 = (uint32_t)min(dst_cap, (uint64_t)0xFFFFFFF0u);
+    // word `at` of the own sub-list of bucket b: one 32 x 32 -> 64 multiply-add (list numbers and capacities fit 32 bits)
+    auto word_of = [&](uint32_t b, uint32_t at) -> uint64_t * { return dst + ((uint64_t)(b * G + wg) * (uint64_t)cap32 + at); };
+    if (tid < 64) s_roll[tid] = p.roll[tid];
+    if (tid < 256) s_lut4[tid] = p.roll[64 + tid];
+    if (tid < 4) {   // hashes of the four homopolymer k-mers, from the global copy of the LUT
+        const uint64_t x = (0x5555555555555555ULL * (uint64_t)tid) & p.top_mask;
+        uint64_t hh = 0;
+        for (int grp = 0; grp < 16; ++grp) hh ^= p.roll[64 + grp * 16 + ((x >> (4 * grp)) & 15u)];
+        s_homh[tid] = hh;
+    }
+    if (tid < (SP_NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
+    if (tid < 3) s_nl[(SP_TILE + HALO) / 64 + tid] = ~0ULL;
+    if (tid < 2) s_codes[(SP_TILE + HALO) / 32 + tid] = 0;
+    if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
+    if (tid < 2) s_njobs[tid] = 0;
+    if (tid == 0) s_ovn = 0;
+    for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_tail[b] = 0; s_head[b] = 0; }
+    uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
+    unsigned long long added = 0;
+    uint32_t spilled = 0;
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t ngrp = (2u * k + 3u) / 4u;
+    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
+
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    auto side_insert = [&](uint64_t hkey, uint64_t d) {
+        if (dbg & 1) return;
+        defer_append1(pk, hkey, d);
+    };
+    // a key that found its sub-list full: spill cache (a hot key hits it), overflow queue, deferred list
+    auto spill = [&](uint64_t key) {
+        ++spilled;
+        const uint64_t kk = key ^ OVF_SALT;
+        if (kk != 0) {
+            const uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot]), 0ULL,
+                                                     (unsigned long long)kk);
+            if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
+        }
+        if (ovq) {
+            const uint32_t at = atomicAdd(&s_ovn, 1u);
+            if (at < ovq_cap) { ovq[at] = key; return; }
+        }
+        side_insert(key, 1);
+    };
+    uint32_t round = 0;
+    // partition_ring_kernel's flush for one-word records and fixed-capacity lists: (A) one thread per list decides
+    // how many words leave (whole 128-B lines of the destination, or everything at the end), (B) an octet of lanes
+    // per list copies them.
+    auto flush = [&](bool all) {
+        const uint32_t par = round & 1u;
+        ++round;
+        if (tid == 0) s_njobs[par ^ 1u] = 0;
+        for (uint32_t b = tid; b < nb; b += SP_NT) {
+            const uint32_t head = s_head[b];
+            const uint32_t tail = min(s_tail[b], head + CAP);   // arrivals past the ring went out directly
+            const uint32_t avail = tail - head;
+            const uint32_t at = s_cur[b];
+            const uint32_t end = (at + avail) & ~(uint32_t)(PART_FLUSH - 1);
+            const uint32_t nout = all ? avail : (end > at ? end - at : 0u);
+            s_meta[b] = ((unsigned long long)at << 16) | ((unsigned long long)(head & cmask) << 8) | nout;
+            s_head[b] = head + nout;
+            s_tail[b] = tail;
+            s_cur[b] = at + nout;
+            if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;
+        }
+        lds_barrier();
+        const uint32_t oct = tid >> 3, ol = tid & 7;
+        const uint32_t njobs = s_njobs[par];
+        // about 45 % of the lists have a line to send after a half strip: two jobs per octet and pass
+        constexpr int ITER = 2;
+        for (uint32_t j0 = 0; j0 < njobs; j0 += ITER * (SP_NT / 8)) {
+            unsigned long long meta[ITER];
+            uint32_t bj[ITER];
+            uint64_t k0[ITER], k1[ITER];
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t j = j0 + oct + u * (SP_NT / 8);
+                bj[u] = (j < njobs) ? s_job[j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t j = j0 + oct + u * (SP_NT / 8);
+                meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
+            }
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
+                const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
+                k0[u] = (ol < nout) ? ring[(hd + ol) & cmask] : 0;
+                k1[u] = (ol + 8 < nout) ? ring[(hd + ol + 8) & cmask] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
+                const uint32_t at = (uint32_t)(meta[u] >> 16);
+                const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
+                uint64_t *out = word_of(bj[u], at);
+                if (ol < nout) { if (at + ol < cap32) out[ol] = k0[u]; else spill(k0[u]); }
+                if (ol + 8 < nout) { if (at + ol + 8 < cap32) out[ol + 8] = k1[u]; else spill(k1[u]); }
+                if (nout > 16)
+                    for (uint32_t q = ol + 16; q < nout; q += 8) {
+                        const uint64_t w = ring[(hd + q) & cmask];
+                        if (at + q < cap32) out[q] = w; else spill(w);
+                    }
+            }
+        }
+    };
+
+    // text of the tile: 16 bytes per lane and "the byte before them is a newline", loaded one tile ahead
+    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
+    bool cur_pnl = true;
+    if ((uint64_t)blockIdx.x < ntiles) {
+        const uint64_t off = (uint64_t)blockIdx.x * SP_TILE + (uint64_t)tid * 16;
+        cur = load16(buf, off, n);
+        cur_pnl = prev_is_nl(buf, off, n, head_open);
+        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
+    }
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * SP_TILE;
+        lds_barrier();  // previous tile's LDS fully consumed (and the last flush's ring reads done)
+        {
+            uint32_t nl, le, code;
+            classify16(cur, cur_pnl, nl, le, code);
+            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
+            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
+            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
+            if (tid < HALO / 16) {
+                uint32_t hnl, hle, hcode;
+                classify16(hcur, false, hnl, hle, hcode);
+                reinterpret_cast<uint32_t *>(s_codes)[SP_TILE / 16 + tid] = hcode;
+                reinterpret_cast<uint16_t *>(s_nl)[SP_TILE / 16 + tid] = (uint16_t)hnl;
+            }
+            const uint32_t c = __popc(le);
+            const uint32_t inc = wave_incl_scan(c);
+            if (lane == 63) s_wsum[wave] = inc;
+            lds_barrier();
+            uint32_t woff = tile_line[tile * (SP_TILE / TILE)];   // the line pre-pass counts per TILE bytes
+            for (uint32_t w = 0; w < wave; ++w) woff += s_wsum[w];
+            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        {
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint64_t off = nt * SP_TILE + (uint64_t)tid * 16;
+                cur = load16(buf, off, n);
+                cur_pnl = prev_is_nl(buf, off, n, head_open);
+                if (tid < HALO / 16) hcur = load16(buf, nt * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
+            }
+        }
+        lds_barrier();
+
+        // ---- this lane's strip: start positions s .. s+15 of the tile (as in scan_log_kernel) -----------
+        const uint32_t s0 = tid * 16;
+        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
+        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
+        uint64_t m;
+        {
+            const uint32_t w = tid >> 1, sh = (tid & 1u) * 16u;
+            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2];
+            m = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
+        }
+        uint64_t r = m;
+        {
+            uint32_t span = 1;
+            while (span * 2 <= k) { r |= r >> span; span *= 2; }
+            if (span < k) r |= r >> (k - span);
+        }
+        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
+        const uint32_t lb = s_lb[tid];
+        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
+        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
+        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
+        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);
+        const uint64_t g0 = base + s0;
+        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
+        const uint32_t nb1m = (p.line_mask & 2u) ? ~b1 : ~0u;
+        const uint32_t vm = ~(uint32_t)r & b0 & nb1m & ((1u << jmax) - 1u);
+        added += (unsigned long long)__popc(vm);
+        const uint32_t cw0 = codes32[tid], cw1 = codes32[tid + 1], cw2 = codes32[tid + 2];
+        const bool wave_has = __ballot(vm != 0u) != 0ULL;   // header, '+' and quality lines: nothing to walk
+        uint64_t h = 0;
+        uint32_t inc = 0, single = 0;
+        if (wave_has) {
+            const uint64_t lo = (uint64_t)cw0 | ((uint64_t)cw1 << 32), hi = cw2;
+            if (vm) {
+                const uint64_t x = lo & p.top_mask;
+                for (uint32_t grp = 0; grp < ngrp; ++grp) h ^= s_lut4[grp * 16u + ((uint32_t)(x >> (4u * grp)) & 15u)];
+            }
+            {
+                const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
+                const uint32_t w0 = (ws == 0u) ? cw0 : (ws == 1u) ? cw1 : cw2;
+                const uint32_t w1 = (ws == 0u) ? cw1 : (ws == 1u) ? cw2 : 0u;
+                inc = __funnelshift_r(w0, w1, sh);
+            }
+            uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
+            {
+                const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
+                uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
+                uint32_t span = 1;
+                while (span * 2 <= k - 1) {
+                    const uint32_t sh = 2u * span;
+                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                    rhi |= rhi >> sh;
+                    span *= 2;
+                }
+                if (span < k - 1) {
+                    const uint32_t sh = 2u * (k - 1 - span);
+                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                }
+                uint32_t x = ~(uint32_t)rlo & 0x55555555u;
+                x = (x | (x >> 1)) & 0x33333333u;
+                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                x = (x | (x >> 4)) & 0x00FF00FFu;
+                homm = (x | (x >> 8)) & 0xFFFFu;
+            }
+            const uint32_t hv = vm & homm;
+            single = vm & ~homm;
+            if (__ballot(hv != 0u)) {
+                for (uint32_t b = 0; b < 4; ++b) {
+                    uint32_t e = cw0 ^ (0x55555555u * b);
+                    uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
+                    y = (y | (y >> 1)) & 0x33333333u;
+                    y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+                    y = (y | (y >> 4)) & 0x00FF00FFu;
+                    y = (y | (y >> 8)) & 0xFFFFu;
+                    uint32_t tot = (uint32_t)__popc(hv & y);
+                    if (__ballot(tot != 0u) == 0ULL) continue;
+                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                    if (lane == 0) {
+                        const uint64_t key = s_homh[b];
+                        uint64_t *hkey = s_hot_key + wave * HOT_N;
+                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                        int at = -1;
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (hcnt[q] && hkey[q] == key) { at = q; break; }
+                        if (at < 0)
+                            for (int q = 0; q < HOT_N; ++q)
+                                if (!hcnt[q]) { at = q; hkey[q] = key; break; }
+                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                        else side_insert(key, tot);
+                    }
+                }
+            }
+        }
+        // ---- the strip in two halves of 8 positions: roll, append to the rings, flush ----------------------
+        for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
+            const uint32_t s8 = (single >> j0) & 0xFFu;
+            if (wave_has) {
+                if (__ballot(s8 != 0u) == 0ULL) {   // nothing to append in this half: only roll on
+                    if (j0 == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
+                                                 (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
+                            h = (h >> 2) ^ s_roll[idx];
+                        }
+                    }
+                } else {
+                    uint64_t hs[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        hs[j] = h;
+                        if (j0 + j < 15) {
+                            const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
+                                                 (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
+                            h = (h >> 2) ^ s_roll[idx];
+                        }
+                    }
+                    // ring places of all eight first (the returning LDS atomics are in flight together), then the keys
+                    uint32_t bq[8], sl[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        bq[j] = (uint32_t)(hs[j] >> shift) & (nb - 1);
+                        sl[j] = ((s8 >> j) & 1u) ? atomicAdd(&s_tail[bq[j]], 1u) : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if ((s8 >> j) & 1u) {
+                            const uint32_t b = bq[j];
+                            if (sl[j] - s_head[b] < CAP) {
+                                s_stage[(b << SP_CAPBITS) + (sl[j] & cmask)] = hs[j];
+                            } else {   // ring full: the next place of the list directly
+                                const uint32_t at = atomicAdd(&s_cur[b], 1u);
+                                if (at < cap32) *word_of(b, at) = hs[j];
+                                else spill(hs[j]);
+                            }
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            flush(false);
+            lds_barrier();
+        }
+    }
+    lds_barrier();
+    flush(true);
+    lds_barrier();
+    for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * G + wg] = min(s_cur[b], cap32);
+    if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) side_insert(s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
+    if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
+    if (tid < (SP_NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    for (int d = 32; d > 0; d >>= 1) { added += __shfl_down(added, d, 64); spilled += __shfl_down(spilled, d, 64); }
+    if (lane == 0) {
+        if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        if (spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
+    }
 }
 
 // Inserts the overflow queues partition_ring_kernel left behind (one queue of `cap` records per

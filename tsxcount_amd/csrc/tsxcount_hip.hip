@@ -479,8 +479,22 @@ extern "C" int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storage
     {
         const void *src = (p.wk == 1) ? (const void *)m->roll : (const void *)m->roll_wide.data();
         const size_t bytes = (size_t)64 * p.wk * 8;
-        HIP_TRY_C(hipMalloc((void **)&m->d_roll, bytes));
+        // one-limb keys: the same mapping as a LUT by 4-bit groups (16 x 16 entries = 2 KiB) behind the roll
+        // table -- scan_part_kernel has no LDS to spare for the 8-bit-group LUT (16 KiB)
+        std::vector<uint64_t> lut4;
+        if (p.wk == 1) {
+            lut4.assign(256, 0);
+            for (int grp = 0; grp < 16; ++grp)
+                for (uint64_t v = 0; v < 16; ++v) {
+                    uint64_t x = (v << (4 * grp)) & p.top_mask, y = 0;
+                    apply_rows(m, m->rows, &x, &y);
+                    lut4[grp * 16 + v] = y;
+                }
+        }
+        HIP_TRY_C(hipMalloc((void **)&m->d_roll, bytes + lut4.size() * 8));
         HIP_TRY_C(hipMemcpy(m->d_roll, src, bytes, hipMemcpyHostToDevice));
+        if (!lut4.empty())
+            HIP_TRY_C(hipMemcpy(m->d_roll + 64, lut4.data(), lut4.size() * 8, hipMemcpyHostToDevice));
         p.roll = m->d_roll;
     }
     rc = clear_impl(m, true);
@@ -604,6 +618,12 @@ struct PartPlan {
     unsigned long long *c_log, *c_rstart, *c_bstart, *c_bcnt, *c_seg, *d_offs;
     uint32_t *d_hist;
     size_t cnt_need;
+    // scan fused with level 1 (scan_part_kernel): G1 workgroups, each with a sub-list of cap1 records per level-1
+    // bucket in buffer 1 (list (b, g) at (b * G1 + g) * cap1), sizes in c_l1[b * G1 + g]
+    bool fused;
+    uint32_t G1;
+    uint64_t cap1;
+    unsigned long long *c_l1;
 };
 
 static inline int rec_words(int wk) { return wk == 3 ? 4 : wk; }
@@ -646,7 +666,7 @@ static int ensure_deferred(tsx_hip_map *m, uint64_t maxrec, hipStream_t st) {
 // maxrec: upper bound of records; g: number of source regions; own_log: the records come from
 // this map's scan kernel (needs the log buffer); hist_nb_override: sharded scan.
 static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, uint32_t hist_nb_override,
-                          hipStream_t st, PartPlan &pl) {
+                          hipStream_t st, PartPlan &pl, int fused_g = 0) {
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
     pl.g = g;
@@ -667,10 +687,20 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     const uint64_t per_sub = maxrec / pl.nseg / pl.cpr2;
     // multiple of 16 records: every sub-list starts on a 128-B line
     pl.cap_sub = (per_sub + per_sub / 4 + 6 * (uint64_t)std::sqrt((double)per_sub + 1.0) + 64 + 15) & ~15ULL;
-    // buffer 0: key log, later the segment sub-lists of a two-level split; buffer 1: packed level-1 output
-    const uint64_t rec_cap = own_log ? (uint64_t)g * pl.log_cap : maxrec;
+    // fused scan + level 1: one-limb keys, two levels (a one-level split feeds the build, which takes <= 8 pieces)
+    pl.fused = fused_g > 0 && pl.b2 > 0 && p.wk == 1 && (fused_g + pl.cpr2 - 1) / pl.cpr2 <= (uint32_t)PART_MAX_PIECES;
+    pl.G1 = pl.fused ? (uint32_t)fused_g : 0;
+    pl.cap1 = 0;
+    if (pl.fused) {
+        const uint64_t per1 = maxrec / pl.nb1 / pl.G1;
+        pl.cap1 = (per1 + per1 / 4 + 6 * (uint64_t)std::sqrt((double)per1 + 1.0) + 64 + 15) & ~15ULL;
+        if (const char *e = getenv("TSX_HIP_CAP1")) pl.cap1 = (uint64_t)std::max(16, atoi(e) & ~15);   // tests: force overflow
+    }
+    // buffer 0: key log, later the segment sub-lists of a two-level split; buffer 1: packed level-1 output, or the
+    // level-1 sub-lists of the fused scan
+    const uint64_t rec_cap = pl.fused ? 0 : (own_log ? (uint64_t)g * pl.log_cap : maxrec);
     const size_t need0 = std::max<uint64_t>(own_log ? rec_cap : 0, pl.b2 ? (uint64_t)pl.nseg * pl.cpr2 * pl.cap_sub : 0) * 8 * pl.rw;
-    const size_t need1 = rec_cap * 8 * pl.rw;
+    const size_t need1 = (pl.fused ? (uint64_t)pl.nb1 * pl.G1 * pl.cap1 : rec_cap) * 8 * pl.rw;
     int rc = grow(st, m->d_buf[0], m->buf_bytes[0], need0);
     if (rc != TSX_HIP_OK) return rc;
     rc = grow(st, m->d_buf[1], m->buf_bytes[1], need1);
@@ -678,7 +708,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     // counters: [region fill | region start | bucket start | bucket size | sub-list size], then the
     // histogram matrix (u32) and its exclusive scan (u64), both max(nb1, hist_nb) x g
     const uint32_t hb = std::max(pl.nb1, pl.hist_nb);
-    pl.cnt_need = 2 * (size_t)g + 2 * (size_t)hb + (size_t)pl.nseg * pl.cpr2;
+    pl.cnt_need = 2 * (size_t)g + 2 * (size_t)hb + (size_t)pl.nseg * pl.cpr2 + (size_t)pl.nb1 * pl.G1;
     const size_t mat = (size_t)hb * g;
     size_t have = m->cnt_entries;
     unsigned long long *ptr = m->d_cnt;
@@ -688,7 +718,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.c_log = m->d_cnt;                    // fill of each log region, or size of each cut of a received array
     pl.c_rstart = pl.c_log + g;
     pl.c_bstart = pl.c_rstart + g; pl.c_bcnt = pl.c_bstart + hb; pl.c_seg = pl.c_bcnt + hb;
-    pl.d_offs = pl.c_seg + (size_t)pl.nseg * pl.cpr2;
+    pl.c_l1 = pl.c_seg + (size_t)pl.nseg * pl.cpr2;
+    pl.d_offs = pl.c_l1 + (size_t)pl.nb1 * pl.G1;
     pl.d_hist = reinterpret_cast<uint32_t *>(pl.d_offs + mat);
     HIP_TRY(hipMemsetAsync(m->d_cnt, 0, pl.cnt_need * 8, st));
     if (!m->attr_done) {   // per map, hence per device: the attribute belongs to the device's copy of the kernel
@@ -707,10 +738,24 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)scan_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         m->attr_done = true;
     }
+    return TSX_HIP_OK;
+}
+
+// Overflow queues (OVQ_CAP records each): one per level-2 workgroup, plus one per workgroup of the fused scan.
+static int ensure_ovq(tsx_hip_map *m, size_t nq, int rw, hipStream_t st) {
+    if (nq * rw <= m->ovq_queues) return TSX_HIP_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (m->d_ovq) HIP_TRY(hipFree(m->d_ovq));
+    if (m->d_ovq_cnt) HIP_TRY(hipFree(m->d_ovq_cnt));
+    m->d_ovq = nullptr; m->d_ovq_cnt = nullptr; m->ovq_queues = 0;
+    HIP_TRY(hipMalloc((void **)&m->d_ovq, nq * OVQ_CAP * 8 * rw));
+    HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, nq * 4));
+    m->ovq_queues = nq * rw;
     return TSX_HIP_OK;
 }
 
@@ -743,6 +788,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         return bits;
     };
     auto part_lds = [](uint32_t nb, uint32_t bits) { return (size_t)nb * (((size_t)8 << bits) + 36); };
+    if (!pl.fused) {
     hipLaunchKernelGGL(offsets_rows_kernel, dim3(pl.nb1), dim3(1024), 0, st, (const uint32_t *)pl.d_hist, pl.d_offs,
                        (uint32_t)pl.g, pl.c_bcnt);
     hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, pl.nb1, pl.c_bstart, pl.c_bcnt);
@@ -752,9 +798,10 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,
                            m->d_buf[1], (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
-                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u));
+                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0));
         HIP_TRY(hipGetLastError());
     }
+    }   // (fused: scan_part_kernel has left the level-1 sub-lists in buffer 1)
     if (ev) HIP_TRY(hipEventRecord(ev[4], st));
     const uint64_t *lists = m->d_buf[1];
     const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
@@ -763,22 +810,18 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     uint32_t nq2 = 0;
     if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
         const uint32_t bits = ring_bits(pl.nb2);
-        nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup
-        if ((size_t)nq2 * rw > m->ovq_queues) {
-            HIP_TRY(hipStreamSynchronize(st));
-            if (m->d_ovq) HIP_TRY(hipFree(m->d_ovq));
-            if (m->d_ovq_cnt) HIP_TRY(hipFree(m->d_ovq_cnt));
-            m->d_ovq = nullptr; m->d_ovq_cnt = nullptr; m->ovq_queues = 0;
-            HIP_TRY(hipMalloc((void **)&m->d_ovq, (size_t)nq2 * OVQ_CAP * 8 * rw));
-            HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, (size_t)nq2 * 4));
-            m->ovq_queues = (size_t)nq2 * rw;
+        nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup (the fused scan's queues follow them)
+        {
+            const int rco = ensure_ovq(m, (size_t)nq2 + pl.G1, rw, st);
+            if (rco != TSX_HIP_OK) return rco;
         }
         DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(RING_NT),
                            part_lds(pl.nb2, bits), st, pp, (const uint64_t *)m->d_buf[1],
                            (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
                            pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg,
-                           m->d_ovq, m->d_ovq_cnt, OVQ_CAP));
+                           m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
+                           pl.G1, pl.cap1));
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
@@ -823,9 +866,10 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     // Records that found their sub-list filled up by a hot key, and the deferred list: inserted now, by the
     // whole chip, into a table whose segments are all in place.
     if (nq2 && !(m->dbg & 1)) {
-        DISPATCH_WK(m, hipLaunchKernelGGL((overflow_insert_kernel<WKV>), dim3(std::min<uint32_t>(nq2, (uint32_t)m->cus * 8)),
+        const uint32_t nq = nq2 + pl.G1;
+        DISPATCH_WK(m, hipLaunchKernelGGL((overflow_insert_kernel<WKV>), dim3(std::min<uint32_t>(nq, (uint32_t)m->cus * 8)),
                                           dim3(PART_NT), 0, st, pp, (const uint64_t *)m->d_ovq,
-                                          (const uint32_t *)m->d_ovq_cnt, OVQ_CAP, nq2));
+                                          (const uint32_t *)m->d_ovq_cnt, OVQ_CAP, nq));
         HIP_TRY(hipGetLastError());
     }
     if (!(m->dbg & 1)) {
@@ -909,7 +953,11 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const int gs = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * scan_wgs);
     const int greg = gs * (NT / 64);
     PartPlan pl;
-    int rc = plan_partition(m, maxrec, greg, true, shard_send ? nown : 0, st, pl);
+    // scan fused with radix level 1 (TSX_HIP_FUSE=0: the key log + separate level 1): local runs, one-limb keys
+    static const int fuse = getenv("TSX_HIP_FUSE") ? atoi(getenv("TSX_HIP_FUSE")) : 1;
+    const uint64_t ntiles_sp = (own_end + SP_TILE - 1) / SP_TILE;
+    const int g_sp = (int)std::min<uint64_t>(ntiles_sp, (uint64_t)m->cus * 2);
+    int rc = plan_partition(m, maxrec, greg, true, shard_send ? nown : 0, st, pl, (fuse && !shard_send && p.wk == 1) ? g_sp : 0);
     if (rc != TSX_HIP_OK) return rc;
     // what cannot take the fast route: the caller's hot list (sharded scan), else the map's deferred list
     TableParams pp = m->p;
@@ -923,7 +971,15 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     }
     // scan -> key log + histogram by level-1 bucket, or by owner GPU for a sharded scan
     const uint32_t hist_nb = shard_send ? nown : pl.nb1, hist_shift = (uint32_t)(shard_send ? p.l : p.l - pl.b1);
-    if (p.wk == 1) {
+    if (pl.fused) {
+        const uint32_t nq2 = pl.nb1 * pl.cpr2;
+        rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
+        if (rc != TSX_HIP_OK) return rc;
+        const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 4 * 4);
+        hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
+                           (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, m->d_buf[1], pl.cap1, pl.c_l1, pl.nb1,
+                           (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
+    } else if (p.wk == 1) {
         hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
                            hist_nb, hist_shift);
