@@ -297,7 +297,10 @@ def main():
         stage_bytes = {"scan": nbytes + (rec_b * keys_logged if partitioned else 2 * slot_b * kmers_rank),
                        "level1": 2 * rec_b * keys_logged, "level2": 2 * rec_b * keys_logged,
                        "build": rec_b * keys_logged + table_bytes}
-        names = {"scan": ("scan_log_kernel" if m.wk == 1 else "scan_log_wide_kernel<%d>" % m.wk) if partitioned
+        # scan fused with radix level 1 (scan_part_kernel): there is no level-1 launch, its stage time is ~0
+        fused = partitioned and m.wk == 1 and stage["level1"] / pieces < 0.05
+        names = {"scan": (("scan_part_kernel" if fused else "scan_log_kernel") if m.wk == 1
+                          else "scan_log_wide_kernel<%d>" % m.wk) if partitioned
                  else "count_fastq_kernel<%d>" % m.wk,
                  "level1": "partition_ring_kernel (level 1)", "level2": "partition_ring_kernel (level 2)",
                  "build": "build_segments_stream_kernel" if (m.wk == 1 and m.layout.entry_limbs == 1)
@@ -342,7 +345,7 @@ def main():
                          "stages": {k2: {"kernel": names[k2], "ms": stage_ms[k2],
                                          "algorithmic_bytes": stage_bytes[k2],
                                          "achieved": stage_bytes[k2] / (stage_ms[k2] * 1e-3) / 1e9 if stage_ms[k2] > 0 else 0.0}
-                                    for k2 in names if stage_ms[k2] > 0},
+                                    for k2 in names if stage_ms[k2] > 0.05},
                          "whole_path": {"algorithmic_bytes": path_bytes, "device_ms": path_ms,
                                         "achieved": path_bytes / (path_ms * 1e-3) / 1e9 if path_ms > 0 else 0.0,
                                         "frac": (path_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_ms > 0 else 0.0}},

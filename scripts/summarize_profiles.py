@@ -64,8 +64,11 @@ for k, v in agg.items():
                               "TCC_EA0_ATOMIC_sum": v.get("TCC_EA0_ATOMIC_sum")}
         tot_r += rd
         tot_w += wr
-scan = part["kernels"].get("tsx::scan_log_kernel", {})
-part["kernel"] = "tsx::scan_log_kernel"
+# the scan kernel: fused with radix level 1 (scan_part_kernel) where the run used it
+SCAN = "tsx::scan_part_kernel" if "tsx::scan_part_kernel" in part["kernels"] else "tsx::scan_log_kernel"
+FUSED = SCAN == "tsx::scan_part_kernel"
+scan = part["kernels"].get(SCAN, {})
+part["kernel"] = SCAN
 part["hbm_bytes_per_launch"] = scan.get("hbm_read_bytes", 0) + scan.get("hbm_write_bytes", 0)
 # bench.py stages: the partition kernel runs twice per step (level 1, then level 2), told apart by dispatch order
 def nth_dispatch_bytes(kernel, nth):
@@ -77,9 +80,9 @@ def nth_dispatch_bytes(kernel, nth):
     if nth >= len(rd) or nth >= len(wr):
         return None
     return rd[nth] * 2048 + wr[nth] * 1024
-part["stages"] = {"scan": nth_dispatch_bytes("tsx::scan_log_kernel", 0),
-                  "level1": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0),
-                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 1),
+part["stages"] = {"scan": nth_dispatch_bytes(SCAN, 0),
+                  "level1": None if FUSED else nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0),
+                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0 if FUSED else 1),
                   "build": nth_dispatch_bytes(BUILD, 0)}
 part["hbm_bytes_whole_path_per_step"] = tot_r + tot_w
 lc = agg.get("tsx::line_count_kernel", {})

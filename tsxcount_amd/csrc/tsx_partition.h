@@ -394,10 +394,11 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
     constexpr uint32_t CAP = 1u << SP_CAPBITS, cmask = CAP - 1;
     uint64_t *s_stage = s_part;
     unsigned long long *s_meta = reinterpret_cast<unsigned long long *>(s_part + ((size_t)nb << SP_CAPBITS));
-    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_meta + nb);   // words written to the own sub-list of the bucket
-    uint32_t *s_tail = s_cur + nb;
-    uint32_t *s_head = s_tail + nb;
-    uint32_t *s_job = s_head + nb;
+    // tail (low word: keys that have asked for a place) and head (high word: keys flushed) of a ring share one
+    // 64-bit word: the returning atomic that takes a place brings the head along, no second LDS read per key
+    unsigned long long *s_th = s_meta + nb;
+    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_th + nb);   // words written to the own sub-list of the bucket
+    uint32_t *s_job = s_cur + nb;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t G = gridDim.x, wg = blockIdx.x;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
     if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
     if (tid < 2) s_njobs[tid] = 0;
     if (tid == 0) s_ovn = 0;
-    for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_tail[b] = 0; s_head[b] = 0; }
+    for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_th[b] = 0; }
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
     unsigned long long added = 0;
     uint32_t spilled = 0;
@@ -456,15 +457,15 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
         ++round;
         if (tid == 0) s_njobs[par ^ 1u] = 0;
         for (uint32_t b = tid; b < nb; b += SP_NT) {
-            const uint32_t head = s_head[b];
-            const uint32_t tail = min(s_tail[b], head + CAP);   // arrivals past the ring went out directly
+            const unsigned long long th = s_th[b];
+            const uint32_t head = (uint32_t)(th >> 32);
+            const uint32_t tail = min((uint32_t)th, head + CAP);   // arrivals past the ring went out directly
             const uint32_t avail = tail - head;
             const uint32_t at = s_cur[b];
             const uint32_t end = (at + avail) & ~(uint32_t)(PART_FLUSH - 1);
             const uint32_t nout = all ? avail : (end > at ? end - at : 0u);
             s_meta[b] = ((unsigned long long)at << 16) | ((unsigned long long)(head & cmask) << 8) | nout;
-            s_head[b] = head + nout;
-            s_tail[b] = tail;
+            s_th[b] = ((unsigned long long)(head + nout) << 32) | tail;
             s_cur[b] = at + nout;
             if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;
         }
@@ -520,10 +521,10 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
         cur_pnl = prev_is_nl(buf, off, n, head_open);
         if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
     }
+    lds_barrier();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t base = tile * SP_TILE;
-        lds_barrier();  // previous tile's LDS fully consumed (and the last flush's ring reads done)
-        {
+        {   // (the previous tile ended with a barrier behind its last flush; the first tile: the one above)
             uint32_t nl, le, code;
             classify16(cur, cur_pnl, nl, le, code);
             reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
@@ -672,18 +673,19 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
                         }
                     }
                     // ring places of all eight first (the returning LDS atomics are in flight together), then the keys
-                    uint32_t bq[8], sl[8];
+                    uint32_t bq[8];
+                    unsigned long long sl[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         bq[j] = (uint32_t)(hs[j] >> shift) & (nb - 1);
-                        sl[j] = ((s8 >> j) & 1u) ? atomicAdd(&s_tail[bq[j]], 1u) : 0u;
+                        sl[j] = ((s8 >> j) & 1u) ? atomicAdd(&s_th[bq[j]], 1ULL) : 0ULL;
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         if ((s8 >> j) & 1u) {
                             const uint32_t b = bq[j];
-                            if (sl[j] - s_head[b] < CAP) {
-                                s_stage[(b << SP_CAPBITS) + (sl[j] & cmask)] = hs[j];
+                            if ((uint32_t)sl[j] - (uint32_t)(sl[j] >> 32) < CAP) {
+                                s_stage[(b << SP_CAPBITS) + ((uint32_t)sl[j] & cmask)] = hs[j];
                             } else {   // ring full: the next place of the list directly
                                 const uint32_t at = atomicAdd(&s_cur[b], 1u);
                                 if (at < cap32) *word_of(b, at) = hs[j];

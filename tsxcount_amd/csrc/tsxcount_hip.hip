@@ -975,7 +975,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         const uint32_t nq2 = pl.nb1 * pl.cpr2;
         rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
         if (rc != TSX_HIP_OK) return rc;
-        const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 4 * 4);
+        const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);   // ring, flush descriptor, tail|head, cursor, job
         hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, m->d_buf[1], pl.cap1, pl.c_l1, pl.nb1,
                            (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
