@@ -330,6 +330,35 @@ def test_hot_keys_overflow_sub_lists_two_radix_levels(T):
     m.close()
 
 
+def test_fused_scan_sub_list_overflow(T, monkeypatch):
+    """scan_part_kernel keeps one fixed-capacity sub-list per (workgroup, level-1 bucket).  Shrunk to 16 keys
+    nearly every key finds its sub-list full and takes the spill cache / overflow queue / deferred list; the
+    counts must not change.  Also the same text with the fused kernel switched off (key log + separate level 1)."""
+    from tsxcount_amd import synth
+    text = synth.fastq(21, 0, 6000)
+    monkeypatch.setenv("TSX_HIP_CAP1", "16")
+    st = assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
+    assert st["fallback_inserts"] > 1000
+    assert_same_as_oracle(T, text, 20, 24, 4, path="partitioned")
+    monkeypatch.delenv("TSX_HIP_CAP1")
+    monkeypatch.setenv("TSX_HIP_FUSE", "0")
+    assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
+    monkeypatch.delenv("TSX_HIP_FUSE")
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"])
+def test_fused_and_unfused_scan_agree_entry_for_entry(T, monkeypatch, fuse):
+    """Two radix levels, pieces of the host entry point (segments rebuilt from their previous content), FASTA
+    records: both forms of the scan must leave the same table."""
+    from tsxcount_amd import synth
+    monkeypatch.setenv("TSX_HIP_FUSE", fuse)
+    monkeypatch.setenv("TSX_HIP_PIECE_BYTES", "300000")
+    text = synth.fastq(33, 0, 5000)
+    assert_same_as_oracle(T, text, 27, 24, 0, path="partitioned")
+    monkeypatch.delenv("TSX_HIP_PIECE_BYTES")
+    monkeypatch.delenv("TSX_HIP_FUSE")
+
+
 def test_stage_timing_hooks(T):
     from tsxcount_amd import synth
     text = synth.fastq(5, 0, 3000)

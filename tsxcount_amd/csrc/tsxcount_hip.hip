@@ -954,7 +954,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const int greg = gs * (NT / 64);
     PartPlan pl;
     // scan fused with radix level 1 (TSX_HIP_FUSE=0: the key log + separate level 1): local runs, one-limb keys
-    static const int fuse = getenv("TSX_HIP_FUSE") ? atoi(getenv("TSX_HIP_FUSE")) : 1;
+    const char *fuse_env = getenv("TSX_HIP_FUSE");   // read per call: the tests run both forms in one process
+    const int fuse = fuse_env ? atoi(fuse_env) : 1;
     const uint64_t ntiles_sp = (own_end + SP_TILE - 1) / SP_TILE;
     const int g_sp = (int)std::min<uint64_t>(ntiles_sp, (uint64_t)m->cus * 2);
     int rc = plan_partition(m, maxrec, greg, true, shard_send ? nown : 0, st, pl, (fuse && !shard_send && p.wk == 1) ? g_sp : 0);
