@@ -79,7 +79,7 @@ constexpr uint32_t OVF_N = 64;
 constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
 
 constexpr int PART_MAX_PIECES = 512;   // pieces of a source region one workgroup may have to walk (src_np / cpr)
-constexpr int PART_ITER = 4;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
+constexpr int PART_ITER = 3;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
 template <int RW>
 __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
@@ -492,8 +492,8 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
             for (int u = 0; u < ITER; ++u) {
                 const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
                 const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
-                k0[u] = (ol < nout) ? ring[(hd + ol) & cmask] : 0;
-                k1[u] = (ol + 8 < nout) ? ring[(hd + ol + 8) & cmask] : 0;
+                k0[u] = (ol < nout) ? ring[((hd + ol) ^ bj[u]) & cmask] : 0;     // (place ^ list: see the append)
+                k1[u] = (ol + 8 < nout) ? ring[((hd + ol + 8) ^ bj[u]) & cmask] : 0;
             }
 #pragma unroll
             for (int u = 0; u < ITER; ++u) {
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
                 if (ol + 8 < nout) { if (at + ol + 8 < cap32) out[ol + 8] = k1[u]; else spill(k1[u]); }
                 if (nout > 16)
                     for (uint32_t q = ol + 16; q < nout; q += 8) {
-                        const uint64_t w = ring[(hd + q) & cmask];
+                        const uint64_t w = ring[((hd + q) ^ bj[u]) & cmask];
                         if (at + q < cap32) out[q] = w; else spill(w);
                     }
             }
@@ -685,7 +685,9 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
                         if ((s8 >> j) & 1u) {
                             const uint32_t b = bq[j];
                             if ((uint32_t)sl[j] - (uint32_t)(sl[j] >> 32) < CAP) {
-                                s_stage[(b << SP_CAPBITS) + ((uint32_t)sl[j] & cmask)] = hs[j];
+                                // place ^ list number: lanes that write the same place of different rings would
+                                // otherwise all hit the same pair of LDS banks (a ring is 32 words = all 64 banks)
+                                s_stage[(b << SP_CAPBITS) + (((uint32_t)sl[j] ^ b) & cmask)] = hs[j];
                             } else {   // ring full: the next place of the list directly
                                 const uint32_t at = atomicAdd(&s_cur[b], 1u);
                                 if (at < cap32) *word_of(b, at) = hs[j];
