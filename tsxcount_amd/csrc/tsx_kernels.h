@@ -403,8 +403,10 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     // first version waited for two dependent loads at the top of every tile)
     uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
     bool cur_pnl = true;
+    uint32_t cur_line = 0;
     if ((uint64_t)blockIdx.x < ntiles) {
         const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
+        cur_line = tile_line[blockIdx.x];
         cur = load16(buf, off, n);
         cur_pnl = prev_is_nl(buf, off, n, head_open);
         if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
             const uint32_t inc = wave_incl_scan(c);
             if (lane == 63) s_wsum[wave] = inc;
             lds_barrier();
-            uint32_t woff = tile_line[tile];
+            uint32_t woff = cur_line;   // lines before the tile, loaded a tile ahead like its text
             for (int w = 0; w < wave; ++w) woff += s_wsum[w];
             s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
         }
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
             const uint64_t nt = tile + gridDim.x;
             if (nt < ntiles) {
                 const uint64_t off = nt * TILE + (uint64_t)tid * 16;
+                cur_line = tile_line[nt];
                 cur = load16(buf, off, n);
                 cur_pnl = prev_is_nl(buf, off, n, head_open);
                 if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
@@ -691,8 +694,10 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
     // text loaded one tile ahead, as in scan_log_kernel
     uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
     bool cur_pnl = true;
+    uint32_t cur_line = 0;
     if ((uint64_t)blockIdx.x < ntiles) {
         const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
+        cur_line = tile_line[blockIdx.x];
         cur = load16(buf, off, n);
         cur_pnl = prev_is_nl(buf, off, n, head_open);
         if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
             const uint32_t inc = wave_incl_scan(c);
             if (lane == 63) s_wsum[wave] = inc;
             lds_barrier();
-            uint32_t woff = tile_line[tile];
+            uint32_t woff = cur_line;   // lines before the tile, loaded a tile ahead like its text
             for (int w = 0; w < wave; ++w) woff += s_wsum[w];
             s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
         }
@@ -724,6 +729,7 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
             const uint64_t nt = tile + gridDim.x;
             if (nt < ntiles) {
                 const uint64_t off = nt * TILE + (uint64_t)tid * 16;
+                cur_line = tile_line[nt];
                 cur = load16(buf, off, n);
                 cur_pnl = prev_is_nl(buf, off, n, head_open);
                 if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);

@@ -515,8 +515,10 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
     // text of the tile: 16 bytes per lane and "the byte before them is a newline", loaded one tile ahead
     uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
     bool cur_pnl = true;
+    uint32_t cur_line = 0;
     if ((uint64_t)blockIdx.x < ntiles) {
         const uint64_t off = (uint64_t)blockIdx.x * SP_TILE + (uint64_t)tid * 16;
+        cur_line = tile_line[(uint64_t)blockIdx.x * (SP_TILE / TILE)];
         cur = load16(buf, off, n);
         cur_pnl = prev_is_nl(buf, off, n, head_open);
         if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
             const uint32_t inc = wave_incl_scan(c);
             if (lane == 63) s_wsum[wave] = inc;
             lds_barrier();
-            uint32_t woff = tile_line[tile * (SP_TILE / TILE)];   // the line pre-pass counts per TILE bytes
+            uint32_t woff = cur_line;   // lines before the tile (the pre-pass counts per TILE bytes), loaded a tile ahead
             for (uint32_t w = 0; w < wave; ++w) woff += s_wsum[w];
             s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
         }
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
             const uint64_t nt = tile + gridDim.x;
             if (nt < ntiles) {
                 const uint64_t off = nt * SP_TILE + (uint64_t)tid * 16;
+                cur_line = tile_line[nt * (SP_TILE / TILE)];
                 cur = load16(buf, off, n);
                 cur_pnl = prev_is_nl(buf, off, n, head_open);
                 if (tid < HALO / 16) hcur = load16(buf, nt * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
