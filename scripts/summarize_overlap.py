@@ -10,7 +10,7 @@ for r in csv.DictReader(open(kf)):
     iv = (int(r["Start_Timestamp"]), int(r["End_Timestamp"]))
     if "scan_log" in n or "split_owner" in n or "line_count" in n:
         scans.append(iv)
-    elif "ccl" in n.lower() or "nccl" in n.lower():
+    elif ("ccl" in n.lower() or "nccl" in n.lower()) and "rocclr" not in n:
         exch.append(iv)
     elif "tsx::" in n:
         others.append(iv)

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap,
-    const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap) {
+    const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap, int dst_bm, unsigned long long *key_sum) {
     constexpr int RPT = (PART_WPT >= RW) ? PART_WPT / RW : 1;   // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
@@ -112,7 +112,11 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     for (uint32_t b = tid; b < nb; b += RING_NT) {
         s_tail[b] = 0; s_head[b] = 0;
         if (offs) { s_cur[b] = (offs_base[b] + offs[(size_t)b * nregions + r]) * RW; s_lim[b] = ~0ULL; }
-        else { s_cur[b] = (((uint64_t)r * nb + b) * cpr + c) * dst_cap * RW; s_lim[b] = s_cur[b] + dst_cap * RW; }
+        else {   // own sub-list of the destination list; dst_bm: numbered bucket-major (the lists of one bucket side by
+                 // side: the next level reads a bucket as nregions * cpr pieces)
+            const uint64_t li = dst_bm ? ((uint64_t)b * nregions + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
+            s_cur[b] = li * dst_cap * RW; s_lim[b] = s_cur[b] + dst_cap * RW;
+        }
     }
     lds_barrier();
     // The source region r: a contiguous run of records (src_start/src_cnt, or src_cap apart), or -- src_pcnt
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         }
     };
     uint64_t cur[RPT][RW], nxt[RPT][RW];
+    unsigned long long ksum = 0;   // sum of the keys read (sharded runs: checked against the sum the scans wrote)
     Batch bc = next_batch();
     load_batch(bc, cur);
     // The first batch must have ARRIVED before the loop: the compiler then knows that `cur` is complete at the
@@ -307,6 +312,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const uint32_t j = (uint32_t)q * RING_NT + tid;
+            if (key_sum && j < bc.nvalid) ksum += cur[q][0];
             bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
             slot[q] = (j < bc.nvalid) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
         }
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     lds_barrier();
     if (dst_cnt)
         for (uint32_t b = tid; b < nb; b += RING_NT) {
-            const uint64_t li = ((uint64_t)r * nb + b) * cpr + c;
+            const uint64_t li = dst_bm ? ((uint64_t)b * nregions + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
             dst_cnt[li] = (min(s_cur[b], s_lim[b]) - li * dst_cap * RW) / RW;
         }
     if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) {   // hot keys: one deferred entry each, with the total
@@ -354,6 +360,10 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
     for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
     if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
+    if (key_sum) {
+        for (int d = 32; d > 0; d >>= 1) ksum += __shfl_down(ksum, d, 64);
+        if ((tid & 63) == 0 && ksum) atomicAdd(key_sum, ksum);
+    }
 }
 
 // ---- scan fused with radix level 1 (one-limb keys, two-level split) -----------------------------------------

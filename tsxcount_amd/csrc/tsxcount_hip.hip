@@ -798,7 +798,8 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,
                            m->d_buf[1], (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
-                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0));
+                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0,
+                           0, (unsigned long long *)nullptr));
         HIP_TRY(hipGetLastError());
     }
     }   // (fused: scan_part_kernel has left the level-1 sub-lists in buffer 1)
@@ -821,7 +822,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg,
                            m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
-                           pl.G1, pl.cap1));
+                           pl.G1, pl.cap1, 0, (unsigned long long *)nullptr));
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
@@ -1108,7 +1109,10 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
     const int g = (int)m->h_regions.size();
     m->h_regions.insert(m->h_regions.end(), cnts.begin(), cnts.end());
     PartPlan pl;
-    int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl);
+    // Level 1 without a histogram pass: every region's workgroup keeps its own fixed-capacity sub-list per bucket
+    // (as level 2 does), level 2 reads a bucket as the regions' pieces -- the plan's `fused` form with G1 = regions.
+    // (One-level tables, many-limb keys: histogram + exact offsets as before.)
+    int rc = plan_partition(m, n_keys + 65536, g, false, 0, st, pl, m->p.wk == 1 ? g : 0);
     if (rc != TSX_HIP_OK) return rc;
     rc = ensure_deferred(m, n_keys + 65536, st);
     if (rc != TSX_HIP_OK) return rc;
@@ -1122,8 +1126,23 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
         HIP_TRY(hipEventRecord(ev[3], st));   // the histogram of the received keys counts as level 1
     }
     if (!m->ev_open.empty()) m->ev_open.pop_front();
-    hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, keys, (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1),
-                       pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
+    if (pl.fused) {
+        const uint32_t nq2 = pl.nb1 * pl.cpr2;
+        rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
+        if (rc != TSX_HIP_OK) return rc;
+        TableParams pp = m->p;
+        pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
+        const uint32_t bits = 5;   // 32-word rings: 16 words may stay behind a flush, 8 arrive per batch on average
+        hipLaunchKernelGGL((partition_ring_kernel<1>), dim3(g), dim3(RING_NT), (size_t)pl.nb1 * (((size_t)8 << bits) + 36), st,
+                           pp, keys, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, (uint64_t)0,
+                           (uint32_t)g, 1u, m->d_buf[1], (const unsigned long long *)nullptr,
+                           (const unsigned long long *)nullptr, pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits,
+                           m->dbg, m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
+                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum);
+    } else {
+        hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, keys, (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1),
+                           pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
+    }
     HIP_TRY(hipGetLastError());
     rc = run_partition_build(m, pl, keys, pl.c_rstart, 0, st, ev);
     if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[7], st));
@@ -1147,9 +1166,18 @@ extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, c
     hipStream_t st = pick_stream(m, stream);
     int rcz = ensure_zeroed(m, st);
     if (rcz != TSX_HIP_OK) return rcz;
-    const int grid = grid_for(m, n, 8);
-    hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
-                       (const uint64_t *)dev_counts, (uint64_t)n, (unsigned long long *)nullptr);
+    if (dev_counts) {
+        // (key, count) lists are the hot lists of the sharded scan: the same few keys over and over (every scan wave
+        // drains its cache).  deferred_insert_kernel sums equal keys of a workgroup's share in LDS first -- one
+        // same-address global atomic per workgroup instead of one per entry (0.36 -> 0.04 ms per window's list).
+        const int grid = (int)std::min<uint64_t>((uint64_t)m->cus * 2, (n + 511) / 512);
+        hipLaunchKernelGGL((deferred_insert_kernel<1>), dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
+                           (const uint64_t *)dev_counts, (const unsigned long long *)nullptr, (uint64_t)n, (uint64_t)n);
+    } else {
+        const int grid = grid_for(m, n, 8);
+        hipLaunchKernelGGL(add_hashed_kernel, dim3(grid), dim3(PART_NT), 0, st, m->p, (const uint64_t *)dev_keys,
+                           (const uint64_t *)dev_counts, (uint64_t)n, (unsigned long long *)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
