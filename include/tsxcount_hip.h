@@ -267,6 +267,17 @@ int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, size_t n_ke
  * them: a build costs a full pass over this GPU's slot range however few keys it brings. */
 int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev_keys, const uint64_t *piece_off,
                                       const uint64_t *piece_cnt, size_t npieces, void *dev_key_sum, void *stream);
+/* Level 1 window by window.  tsx_hip_shard_l1_window_device partitions the n_keys received keys of exchange
+ * window `window` (of nwindows) by radix level 1 as soon as they have arrived -- the later windows are still being
+ * exchanged -- into sub-lists of its own (window 0 plans for est_total_keys keys in all; more than that is not an
+ * error, only slower).  tsx_hip_shard_build_l1_device then runs level 2 + the build over what the windows left:
+ * only these two wait for the last window.  tsx_hip_shard_l1_supported: one-limb keys and a table split by two
+ * radix levels (otherwise: tsx_hip_shard_build_pieces_device). */
+int tsx_hip_shard_l1_supported(tsx_hip_map *m);
+int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, uint32_t window, uint32_t nwindows,
+                                   size_t est_total_keys, void *dev_key_sum, void *stream);
+int tsx_hip_shard_build_l1_device(tsx_hip_map *m, void *stream);
+
 int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
                               void *stream);
 

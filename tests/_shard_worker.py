@@ -22,7 +22,9 @@ torch.cuda.set_device(0)
 bits = world.bit_length() - 1
 # windows > 1: the text is cut at multiples of 4 KiB, inside lines and records; every window's keys take
 # their own exchange while the next window is scanned
-for k, l, n_reads, windows in ((31, 17, 240, 3), (21, 15, 30, 1), (32, 19, 700, 5)):
+# l = 23: a table split by two radix levels -- level 1 of the received keys then runs window by window
+# (tsx_hip_shard_l1_window_device), level 2 + build once at the end
+for k, l, n_reads, windows in ((31, 17, 240, 3), (21, 15, 30, 1), (32, 19, 700, 5), (31, 23, 1500, 3)):
     first, cnt = TD.shard_reads(n_reads, rank, world)
     text = synth.fastq(66, first, cnt)
     buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")

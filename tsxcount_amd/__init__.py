@@ -80,6 +80,9 @@ def lib():
     L.tsx_hip_shard_build_device.argtypes = [vp, vp, sz, vp, vp]
     L.tsx_hip_shard_build_pieces_device.argtypes = [vp, vp, u64p, u64p, sz, vp, vp]
     L.tsx_hip_add_hashed_device.argtypes = [vp, vp, vp, sz, vp]
+    L.tsx_hip_shard_l1_supported.argtypes = [vp]
+    L.tsx_hip_shard_l1_window_device.argtypes = [vp, vp, sz, ctypes.c_uint32, ctypes.c_uint32, sz, vp, vp]
+    L.tsx_hip_shard_build_l1_device.argtypes = [vp, vp]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None
     L.tsx_hip_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]

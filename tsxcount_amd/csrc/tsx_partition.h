@@ -86,7 +86,8 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap,
-    const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap, int dst_bm, unsigned long long *key_sum) {
+    const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap, int dst_bm, unsigned long long *key_sum,
+    uint32_t dst_r0, uint32_t dst_nr) {
     constexpr int RPT = (PART_WPT >= RW) ? PART_WPT / RW : 1;   // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         if (offs) { s_cur[b] = (offs_base[b] + offs[(size_t)b * nregions + r]) * RW; s_lim[b] = ~0ULL; }
         else {   // own sub-list of the destination list; dst_bm: numbered bucket-major (the lists of one bucket side by
                  // side: the next level reads a bucket as nregions * cpr pieces)
-            const uint64_t li = dst_bm ? ((uint64_t)b * nregions + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
+            // (dst_r0, dst_nr: this launch partitions regions dst_r0 .. of dst_nr in all -- one launch per exchange window)
+            const uint64_t li = dst_bm ? ((uint64_t)b * dst_nr + dst_r0 + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
             s_cur[b] = li * dst_cap * RW; s_lim[b] = s_cur[b] + dst_cap * RW;
         }
     }
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     lds_barrier();
     if (dst_cnt)
         for (uint32_t b = tid; b < nb; b += RING_NT) {
-            const uint64_t li = dst_bm ? ((uint64_t)b * nregions + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
+            const uint64_t li = dst_bm ? ((uint64_t)b * dst_nr + dst_r0 + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
             dst_cnt[li] = (min(s_cur[b], s_lim[b]) - li * dst_cap * RW) / RW;
         }
     if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) {   // hot keys: one deferred entry each, with the total

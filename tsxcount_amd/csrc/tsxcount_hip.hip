@@ -39,6 +39,9 @@ static int scan_wg_per_cu() {  // scan_log_kernel workgroups per CU: 5 are resid
 static const uint32_t OVQ_CAP = 2048;  // keys per overflow queue (one queue per level-2 workgroup: 32 MiB at 2048 workgroups)
 static const size_t STAGE_PIECE_DEFAULT = (size_t)64 << 20;  // bytes of FASTQ per host piece
 
+struct PartPlan;
+struct tsx_hip_map;
+static void drop_sh_plan(tsx_hip_map *m);
 struct tsx_hip_map {
     TableParams p{};
     tsx_hip_layout lay{};
@@ -88,6 +91,12 @@ struct tsx_hip_map {
                                      // partition phase (later than the scan's end only in a sharded run: the
                                      // exchange lies between), after level 1, level 2, build
     std::vector<unsigned long long> h_regions;   // host copy of the region table of a sharded build (starts, then sizes)
+    PartPlan *sh_pl = nullptr;                   // sharded run, level 1 per exchange window: the plan made at window 0,
+    uint32_t sh_rw = 0, sh_windows = 0;          // regions per window, windows of the step,
+    uint64_t *sh_buf1 = nullptr;                 // and its own sub-list buffer and counters (the scans of the later
+    size_t sh_buf1_bytes = 0;                    // windows plan with -- and clear -- the map's while level 1 of the
+    unsigned long long *sh_cnt = nullptr;        // earlier ones has already left its sizes there)
+    size_t sh_cnt_entries = 0;
     std::deque<long> ev_open;        // tuples of shard scans whose partition phase has not run yet (oldest first)
     size_t ev_used = 0;
 };
@@ -509,6 +518,8 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
+    drop_sh_plan(m);
+    (void)hipFree(m->sh_buf1); (void)hipFree(m->sh_cnt);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
     (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt); (void)hipFree(m->d_small);
     (void)hipFree(m->d_def_rec); (void)hipFree(m->d_def_cnt); (void)hipFree(m->d_def_n);
@@ -624,7 +635,10 @@ struct PartPlan {
     uint32_t G1;
     uint64_t cap1;
     unsigned long long *c_l1;
+    uint64_t *buf1;              // buffer 1 of this plan (the map's, or the window-wise sharded level 1's own)
 };
+
+static void drop_sh_plan(tsx_hip_map *m) { delete m->sh_pl; m->sh_pl = nullptr; }
 
 static inline int rec_words(int wk) { return wk == 3 ? 4 : wk; }
 
@@ -705,6 +719,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     if (rc != TSX_HIP_OK) return rc;
     rc = grow(st, m->d_buf[1], m->buf_bytes[1], need1);
     if (rc != TSX_HIP_OK) return rc;
+    pl.buf1 = m->d_buf[1];
     // counters: [region fill | region start | bucket start | bucket size | sub-list size], then the
     // histogram matrix (u32) and its exclusive scan (u64), both max(nb1, hist_nb) x g
     const uint32_t hb = std::max(pl.nb1, pl.hist_nb);
@@ -796,15 +811,15 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         const uint32_t bits = ring_bits(pl.nb1);
         DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.g), dim3(RING_NT), part_lds(pl.nb1, bits), st,
                            pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,
-                           m->d_buf[1], (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
+                           pl.buf1, (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
                            (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0,
-                           0, (unsigned long long *)nullptr));
+                           0, (unsigned long long *)nullptr, 0u, 0u));
         HIP_TRY(hipGetLastError());
     }
     }   // (fused: scan_part_kernel has left the level-1 sub-lists in buffer 1)
     if (ev) HIP_TRY(hipEventRecord(ev[4], st));
-    const uint64_t *lists = m->d_buf[1];
+    const uint64_t *lists = pl.buf1;
     const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
     uint64_t lists_cap = 0;
     uint32_t pieces = 1;
@@ -817,12 +832,12 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
             if (rco != TSX_HIP_OK) return rco;
         }
         DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(RING_NT),
-                           part_lds(pl.nb2, bits), st, pp, (const uint64_t *)m->d_buf[1],
+                           part_lds(pl.nb2, bits), st, pp, (const uint64_t *)pl.buf1,
                            (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
                            pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg,
                            m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
-                           pl.G1, pl.cap1, 0, (unsigned long long *)nullptr));
+                           pl.G1, pl.cap1, 0, (unsigned long long *)nullptr, 0u, 0u));
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
@@ -979,7 +994,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         if (rc != TSX_HIP_OK) return rc;
         const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);   // ring, flush descriptor, tail|head, cursor, job
         hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
-                           (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, m->d_buf[1], pl.cap1, pl.c_l1, pl.nb1,
+                           (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                            (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
     } else if (p.wk == 1) {
         hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
@@ -1135,10 +1150,10 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
         const uint32_t bits = 5;   // 32-word rings: 16 words may stay behind a flush, 8 arrive per batch on average
         hipLaunchKernelGGL((partition_ring_kernel<1>), dim3(g), dim3(RING_NT), (size_t)pl.nb1 * (((size_t)8 << bits) + 36), st,
                            pp, keys, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, (uint64_t)0,
-                           (uint32_t)g, 1u, m->d_buf[1], (const unsigned long long *)nullptr,
+                           (uint32_t)g, 1u, pl.buf1, (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits,
                            m->dbg, m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum);
+                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum, 0u, (uint32_t)g);
     } else {
         hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, keys, (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1),
                            pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
@@ -1155,6 +1170,91 @@ extern "C" int tsx_hip_shard_build_device(tsx_hip_map *m, const void *dev_keys, 
     if (n_keys == 0) return TSX_HIP_OK;
     const uint64_t off = 0, cnt = n_keys;
     return tsx_hip_shard_build_pieces_device(m, dev_keys, &off, &cnt, 1, dev_key_sum, stream);
+}
+
+// ---- sharded run, level 1 window by window ------------------------------------------------------------------
+// The keys of exchange window w are partitioned by level 1 as soon as they have arrived (the exchange of the later
+// windows is still running); only level 2 and the build wait for the last window.
+extern "C" int tsx_hip_shard_l1_supported(tsx_hip_map *m) {
+    if (!m || !can_partition(m) || m->p.wk != 1 || m->p.W != 1) return 0;
+    const int nsegbits = m->p.l - m->p.S;
+    const int b1 = std::min(9, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
+    return nsegbits - b1 > 0 ? 1 : 0;
+}
+
+extern "C" int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_keys, size_t n_keys, uint32_t window,
+                                              uint32_t nwindows, size_t est_total_keys, void *dev_key_sum, void *stream) {
+    if (!m || (!dev_keys && n_keys) || ((uintptr_t)dev_keys & 7) || nwindows == 0 || window >= nwindows) return TSX_HIP_EINVAL;
+    if (!tsx_hip_shard_l1_supported(m)) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    if (!m->sh_pl) m->sh_pl = new PartPlan();
+    PartPlan &pl = *m->sh_pl;
+    if (window == 0) {
+        // one workgroup per region, two workgroups per CU: every window's launch fills the chip once
+        m->sh_rw = (uint32_t)std::min<uint64_t>((uint64_t)m->cus * 2, (uint64_t)PART_MAX_PIECES * 8 / nwindows);
+        m->sh_windows = nwindows;
+        const int g1 = (int)(m->sh_rw * nwindows);
+        const uint64_t maxrec = std::max<uint64_t>(est_total_keys, n_keys) + 65536;
+        std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
+        std::swap(m->d_cnt, m->sh_cnt); std::swap(m->cnt_entries, m->sh_cnt_entries);
+        int rc = plan_partition(m, maxrec, g1, false, 0, st, pl, g1);
+        std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
+        std::swap(m->d_cnt, m->sh_cnt); std::swap(m->cnt_entries, m->sh_cnt_entries);
+        if (rc != TSX_HIP_OK) return rc;
+        if (!pl.fused) return TSX_HIP_EINVAL;
+        rc = ensure_deferred(m, maxrec, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_def_n, 0, 8, st));
+        const uint32_t nq2 = pl.nb1 * pl.cpr2;
+        rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_ovq_cnt, 0, ((size_t)nq2 + pl.G1) * 4, st));   // queues of windows that never run
+        m->h_regions.assign((size_t)2 * g1, 0);
+    } else if (m->sh_windows != nwindows || !pl.fused) {
+        return TSX_HIP_EINVAL;
+    }
+    if (n_keys == 0) return TSX_HIP_OK;
+    // the window's keys in sh_rw equal runs
+    const uint32_t rw = m->sh_rw, g1 = pl.G1;
+    const uint64_t len = (n_keys + rw - 1) / rw;
+    unsigned long long *hs = m->h_regions.data() + (size_t)window * rw, *hc = m->h_regions.data() + g1 + (size_t)window * rw;
+    for (uint32_t r = 0; r < rw; ++r) {
+        const uint64_t o = std::min<uint64_t>((uint64_t)r * len, n_keys);
+        hs[r] = o;
+        hc[r] = std::min<uint64_t>(len, n_keys - o);
+    }
+    unsigned long long *ds = pl.c_rstart + (size_t)window * rw, *dc = pl.c_log + (size_t)window * rw;
+    HIP_TRY(hipMemcpyAsync(ds, hs, (size_t)rw * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dc, hc, (size_t)rw * 8, hipMemcpyHostToDevice, st));
+    TableParams pp = m->p;
+    pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
+    const uint32_t nq2 = pl.nb1 * pl.cpr2, bits = 5;
+    hipLaunchKernelGGL((partition_ring_kernel<1>), dim3(rw), dim3(RING_NT), (size_t)pl.nb1 * (((size_t)8 << bits) + 36), st, pp,
+                       (const uint64_t *)dev_keys, (const unsigned long long *)ds, (const unsigned long long *)dc, (uint64_t)0, rw,
+                       1u, pl.buf1, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, pl.c_l1,
+                       pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits, m->dbg,
+                       m->d_ovq + ((size_t)nq2 + (size_t)window * rw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)window * rw, OVQ_CAP,
+                       (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, (unsigned long long *)dev_key_sum,
+                       window * rw, g1);
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+// level 2 + build over the sub-lists the windows' level-1 launches have filled
+extern "C" int tsx_hip_shard_build_l1_device(tsx_hip_map *m, void *stream) {
+    if (!m || !m->sh_pl || !m->sh_pl->fused) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    hipEvent_t *ev = nullptr;
+    if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
+        ev = &m->ev[(size_t)m->ev_open.front()];
+        HIP_TRY(hipEventRecord(ev[3], st));
+    }
+    if (!m->ev_open.empty()) m->ev_open.pop_front();
+    int rc = run_partition_build(m, *m->sh_pl, nullptr, nullptr, 0, st, ev);
+    if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[7], st));
+    return rc;
 }
 
 extern "C" int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,

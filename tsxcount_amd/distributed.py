@@ -201,7 +201,7 @@ class ShardedCounter:
     slots (TSXHashMapHIP(..., shard_bits=log2 world, shard_index=r)).  step() counts one
     device text of this rank's reads, cut into W windows:
 
-        compute stream   scan(0) scan(1) scan(2) ... scan(W-1)            build
+        compute stream   scan(0) scan(1) l1(0) scan(2) l1(1) ... l1(W-1)  build
         exchange stream        sizes(0) a2a(0)  sizes(1) a2a(1) ... a2a(W-1)
 
     scan(i)   tsx_hip_shard_scan_window_device: window i of the text -> keys grouped by owner
@@ -211,8 +211,10 @@ class ShardedCounter:
               waits while scan(i+1) is already queued on the GPU
     a2a(i)    ONE all_to_all_single with split sizes, from the send buffer into window i's part of
               the receive buffer, behind the own keys; hot lists by all-gather (owners pick theirs)
-    build     ONE tsx_hip_shard_build_pieces_device over all windows' keys (a build costs a pass
-              over the whole slot range, however few keys it brings), then the hot lists
+    l1(i)     tsx_hip_shard_l1_window_device: radix level 1 over window i's received keys as soon as they
+              are here (compute stream, behind scan(i+1)); tables that need one level only: not at all
+    build     ONE tsx_hip_shard_build_l1_device (level 2 + build) over all windows' keys (a build costs a
+              pass over the whole slot range, however few keys it brings), then the hot lists
 
     The exchange of window i overlaps the scan of window i+1; two send and hot buffers alternate.
     Integrity: every scan adds the sum of the keys it wrote, the build the sum of the keys it
@@ -281,6 +283,8 @@ class ShardedCounter:
             self.sums.zero_()
         failure = None
         piece_off, piece_cnt, hot_g = [], [], []
+        l1_windows = bool(L.tsx_hip_shard_l1_supported(m.handle)) and os.environ.get("TSX_HIP_SHARD_L1_WINDOWS", "1") != "0"
+        est_total = 0
         rc_scan = self._scan(0, text_ptr, nbytes)
         for i in range(nwin):
             b = i & 1
@@ -330,14 +334,27 @@ class ShardedCounter:
             piece_off.append(i * self.part)
             piece_cnt.append(n_recv if failure is None else 0)
             hot_g.append(g)
+            if l1_windows and failure is None:
+                # level 1 of window i as soon as its keys are here, behind the scan of window i+1 on the compute stream
+                self.cs.wait_event(self.ev_exch[b])
+                if i == 0:
+                    est_total = int(n_recv * nwin * 1.1)
+                rc = L.tsx_hip_shard_l1_window_device(m.handle, vp(self.recv.data_ptr() + i * self.part * 8), n_recv, i, nwin,
+                                                      est_total, vp(self.sums[1:].data_ptr()), vp(self.cs.cuda_stream))
+                if rc != OK:
+                    failure = (i, [rc])
+                    break
         # ---- ONE partition + build over everything this rank owns, then the hot (key, count) lists
         n_recv_total = sum(piece_cnt)
         self.cs.wait_stream(self.xs)
         if failure is None:
             po = (ctypes.c_uint64 * len(piece_off))(*piece_off)
             pc = (ctypes.c_uint64 * len(piece_cnt))(*piece_cnt)
-            rc = L.tsx_hip_shard_build_pieces_device(m.handle, vp(self.recv.data_ptr()), po, pc, len(piece_off),
-                                                     vp(self.sums[1:].data_ptr()), vp(self.cs.cuda_stream))
+            if l1_windows:
+                rc = L.tsx_hip_shard_build_l1_device(m.handle, vp(self.cs.cuda_stream)) if n_recv_total else OK
+            else:
+                rc = L.tsx_hip_shard_build_pieces_device(m.handle, vp(self.recv.data_ptr()), po, pc, len(piece_off),
+                                                         vp(self.sums[1:].data_ptr()), vp(self.cs.cuda_stream))
             for i, g in enumerate(hot_g):
                 if rc == OK and g:
                     rc = L.tsx_hip_add_hashed_device(m.handle, vp(self.hot_all_k[i].data_ptr()),
