@@ -132,6 +132,17 @@ int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t n);
 int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream);
 
 /*
+ * Blocked gzip (BGZF, `bgzip`) input -- FastXReader.h:178-206 reads `.gz` through zlib (gzopen / gzgets), which
+ * takes a BGZF file as ordinary multi-member gzip.  Here the members are found on the host (BC extra field) and
+ * inflated ON THE DEVICE, one member per lane, CRC-32 and ISIZE of every member checked; the text never exists in
+ * host memory.  tsx_hip_bgzf_index_host: TSX_HIP_EINVAL when the buffer is not BGZF (single-stream gzip: inflate it
+ * with zlib and call tsx_hip_count_fastq_host).  tsx_hip_inflate_bgzf_host returns the inflated bytes (tests, tools).
+ */
+int tsx_hip_bgzf_index_host(const void *gz, size_t n, size_t *members, size_t *text_bytes);
+int tsx_hip_inflate_bgzf_host(int device, const void *gz, size_t n, void *out_host, size_t out_cap, size_t *out_bytes);
+int tsx_hip_count_fastq_bgzf_host(tsx_hip_map *m, const void *gz, size_t n);
+
+/*
  * Lines per record of the texts handed to the count_fastq / shard_scan entry points: 4 = FASTQ
  * (FASTQEntry, FastXReader.h:62-95; the default), 2 = FASTA exactly as FASTXreader<FASTAEntry> reads it
  * (FastXReader.h:97-116: header line, ONE sequence line; sequences wrapped over several lines are not

@@ -80,6 +80,9 @@ def lib():
     L.tsx_hip_shard_build_device.argtypes = [vp, vp, sz, vp, vp]
     L.tsx_hip_shard_build_pieces_device.argtypes = [vp, vp, u64p, u64p, sz, vp, vp]
     L.tsx_hip_add_hashed_device.argtypes = [vp, vp, vp, sz, vp]
+    L.tsx_hip_bgzf_index_host.argtypes = [vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    L.tsx_hip_inflate_bgzf_host.argtypes = [ctypes.c_int, vp, sz, vp, sz, ctypes.POINTER(sz)]
+    L.tsx_hip_count_fastq_bgzf_host.argtypes = [vp, vp, sz]
     L.tsx_hip_shard_l1_supported.argtypes = [vp]
     L.tsx_hip_shard_l1_window_device.argtypes = [vp, vp, sz, ctypes.c_uint32, ctypes.c_uint32, sz, vp, vp]
     L.tsx_hip_shard_build_l1_device.argtypes = [vp, vp]
@@ -276,6 +279,11 @@ class TSXHashMapHIP:
         b = bytes(data)
         _check(self._lib.tsx_hip_count_fastq_host(self._h, b, len(b)))
 
+    def countFastqBgzf(self, gz):
+        """The same for the image of a blocked gzip (BGZF) file: members inflated on the device (tsx_inflate.h)."""
+        b = bytes(gz)
+        _check(self._lib.tsx_hip_count_fastq_bgzf_host(self._h, b, len(b)))
+
     def countFastqDevice(self, dev_ptr, nbytes, stream=None):
         _check(self._lib.tsx_hip_count_fastq_device(self._h, ctypes.c_void_p(dev_ptr), nbytes,
                                                     ctypes.c_void_p(stream) if stream else None))
@@ -344,6 +352,44 @@ class TSXHashMapHIP:
         for i, it in enumerate(items):
             out[i] = encode(it, self.k) if isinstance(it, (str, bytes)) else np.asarray(it, dtype=np.uint64)
         return out
+
+
+def bgzf_index(gz):
+    """(members, text bytes) of a BGZF image, or None when the buffer is not BGZF."""
+    b = bytes(gz)
+    nm, nb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = lib().tsx_hip_bgzf_index_host(b, len(b), ctypes.byref(nm), ctypes.byref(nb))
+    return (nm.value, nb.value) if rc == OK else None
+
+
+def bgzf_inflate(gz, device=0):
+    """Inflate a BGZF image on the device and return the text (tests, tools)."""
+    b = bytes(gz)
+    ix = bgzf_index(b)
+    if ix is None:
+        raise TSXException(EINVAL, "not a BGZF image")
+    out = ctypes.create_string_buffer(max(ix[1], 1))
+    got = ctypes.c_size_t(0)
+    _check(lib().tsx_hip_inflate_bgzf_host(device, b, len(b), out, ix[1], ctypes.byref(got)))
+    return out.raw[:got.value]
+
+
+def bgzf_compress(data, level=6, block=65280):
+    """BGZF writer (the layout `bgzip` produces: SAM specification section 4.1) -- for tests and tools; zlib does
+    the deflate, one gzip member with a BC extra field per `block` bytes, the empty end-of-file member last."""
+    import struct
+    import zlib
+    out = bytearray()
+    data = bytes(data)
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = c.compress(chunk) + c.flush()
+        assert len(raw) + 26 <= 65536
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(raw) + 25)
+                + raw + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    return bytes(out)
 
 
 def synth_sizes(seed, first_read, n_reads, k, want_polya=False):

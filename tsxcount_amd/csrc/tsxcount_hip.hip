@@ -4,6 +4,7 @@
 #include "../../include/tsxcount_hip.h"
 #include "tsx_kernels.h"
 #include "tsx_partition.h"
+#include "tsx_inflate.h"
 
 #include <hip/hip_runtime.h>
 
@@ -1361,6 +1362,155 @@ extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, 
         if (n == 0) break;
     }
     return TSX_HIP_OK;
+}
+
+// ---- blocked gzip (BGZF) input: members found on the host, inflated on the device (tsx_inflate.h) ---------
+struct BgzfIndex {
+    std::vector<uint64_t> in_off, out_off;
+    std::vector<uint32_t> in_len, out_len, crc;
+    uint64_t text_bytes = 0;
+};
+static inline uint32_t le16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+static inline uint32_t le32(const uint8_t *p) { return le16(p) | (le16(p + 2) << 16); }
+
+// gzip members (RFC 1952) that all carry the BGZF 'BC' extra subfield (SAM specification, section 4.1):
+// BSIZE = size of the member - 1.  false: not BGZF (or damaged) -- the caller reads it with zlib instead.
+static bool bgzf_index(const uint8_t *gz, size_t n, BgzfIndex &ix) {
+    size_t o = 0;
+    while (o < n) {
+        if (n - o < 18 || gz[o] != 0x1f || gz[o + 1] != 0x8b || gz[o + 2] != 8 || !(gz[o + 3] & 4)) return false;
+        if (gz[o + 3] & ~4) return false;   // FNAME/FCOMMENT/FHCRC: not written by bgzip, not parsed here
+        const uint32_t xlen = le16(gz + o + 10);
+        if (n - o < 12 + (size_t)xlen + 8) return false;
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const uint8_t *e = gz + o + 12 + x;
+            const uint32_t slen = le16(e + 2);
+            if (e[0] == 'B' && e[1] == 'C' && slen == 2 && x + 6 <= xlen) { bsize = le16(e + 4); found = true; }
+            x += 4 + slen;
+        }
+        if (!found) return false;
+        const size_t total = (size_t)bsize + 1;
+        if (total < 12 + (size_t)xlen + 8 || total > n - o) return false;
+        const size_t data_off = o + 12 + xlen, data_len = total - (12 + xlen) - 8;
+        const uint32_t isize = le32(gz + o + total - 4);
+        if (isize > (1u << 16)) return false;   // a BGZF member holds at most 64 KiB
+        ix.in_off.push_back(data_off);
+        ix.in_len.push_back((uint32_t)data_len);
+        ix.out_off.push_back(ix.text_bytes);
+        ix.out_len.push_back(isize);
+        ix.crc.push_back(le32(gz + o + total - 8));
+        ix.text_bytes += isize;
+        o += total;
+    }
+    return !ix.in_off.empty();
+}
+
+extern "C" int tsx_hip_bgzf_index_host(const void *gz, size_t n, size_t *members, size_t *text_bytes) {
+    if (!gz && n) return TSX_HIP_EINVAL;
+    BgzfIndex ix;
+    if (!bgzf_index((const uint8_t *)gz, n, ix)) return TSX_HIP_EINVAL;
+    if (members) *members = ix.in_off.size();
+    if (text_bytes) *text_bytes = (size_t)ix.text_bytes;
+    return TSX_HIP_OK;
+}
+
+// gz (host) -> inflated text in *d_text (device, 16-byte aligned, text_bytes + 256 bytes; the caller frees it)
+static int inflate_bgzf_to_device(const uint8_t *gz, size_t n, hipStream_t st, uint8_t **d_text, size_t *text_bytes) {
+    BgzfIndex ix;
+    if (!bgzf_index(gz, n, ix)) { g_last_error = "not a BGZF file (no BC extra field in every gzip member)"; return TSX_HIP_EINVAL; }
+    const size_t nm = ix.in_off.size();
+    uint8_t *d_gz = nullptr, *d_out = nullptr, *d_ix = nullptr;
+    uint32_t crc_tab[256];
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int b = 0; b < 8; ++b) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        crc_tab[i] = c;
+    }
+    // one allocation for the index: in_off | out_off | in_len | out_len | crc | status | crc table
+    const size_t ix_bytes = nm * (8 + 8 + 4 + 4 + 4 + 4) + 1024;
+    auto cleanup = [&]() { (void)hipFree(d_gz); (void)hipFree(d_ix); };
+#define HIP_TRY_I(expr)                                                                             \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            cleanup(); (void)hipFree(d_out);                                                        \
+            return (_e == hipErrorOutOfMemory) ? TSX_HIP_ENOMEM : TSX_HIP_EHIP;                     \
+        }                                                                                           \
+    } while (0)
+    HIP_TRY_I(hipMalloc((void **)&d_gz, n + 16));
+    HIP_TRY_I(hipMalloc((void **)&d_out, ix.text_bytes + 256));
+    HIP_TRY_I(hipMalloc((void **)&d_ix, ix_bytes));
+    uint64_t *d_in_off = (uint64_t *)d_ix, *d_out_off = d_in_off + nm;
+    uint32_t *d_in_len = (uint32_t *)(d_out_off + nm), *d_out_len = d_in_len + nm, *d_crc = d_out_len + nm,
+             *d_status = d_crc + nm, *d_tab = d_status + nm;
+    HIP_TRY_I(hipMemcpyAsync(d_gz, gz, n, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_in_off, ix.in_off.data(), nm * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_out_off, ix.out_off.data(), nm * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_in_len, ix.in_len.data(), nm * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_out_len, ix.out_len.data(), nm * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_crc, ix.crc.data(), nm * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_tab, crc_tab, 1024, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemsetAsync(d_status, 0xFF, nm * 4, st));
+    HIP_TRY_I(hipMemsetAsync(d_out + ix.text_bytes, '\n', 256, st));
+    HIP_TRY_I(hipFuncSetAttribute((const void *)inflate_members_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)INF_LDS_BYTES));
+    hipLaunchKernelGGL(inflate_members_kernel, dim3((uint32_t)((nm + INF_NT - 1) / INF_NT)), dim3(INF_NT), INF_LDS_BYTES, st,
+                       (const uint8_t *)d_gz, (const uint64_t *)d_in_off, (const uint32_t *)d_in_len,
+                       (const uint64_t *)d_out_off, (const uint32_t *)d_out_len, (const uint32_t *)d_crc, (uint32_t)nm, d_out,
+                       d_status, (const uint32_t *)d_tab);
+    HIP_TRY_I(hipGetLastError());
+    std::vector<uint32_t> status(nm);
+    HIP_TRY_I(hipMemcpyAsync(status.data(), d_status, nm * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY_I(hipStreamSynchronize(st));
+#undef HIP_TRY_I
+    cleanup();
+    for (size_t i = 0; i < nm; ++i)
+        if (status[i] != INF_OK) {
+            static const char *why[] = {"ok", "deflate data truncated", "reserved block type", "stored block length check",
+                                        "bad code lengths", "invalid symbol", "output overrun or distance too far",
+                                        "size differs from ISIZE", "CRC-32 mismatch"};
+            g_last_error = "BGZF member " + std::to_string(i) + ": " + (status[i] < 9 ? why[status[i]] : "not decoded");
+            (void)hipFree(d_out);
+            return TSX_HIP_EINVAL;
+        }
+    *d_text = d_out;
+    *text_bytes = (size_t)ix.text_bytes;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_inflate_bgzf_host(int device, const void *gz, size_t n, void *out_host, size_t out_cap,
+                                         size_t *out_bytes) {
+    if ((!gz && n) || !out_bytes) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d_text = nullptr;
+    size_t nb = 0;
+    int rc = inflate_bgzf_to_device((const uint8_t *)gz, n, nullptr, &d_text, &nb);
+    if (rc != TSX_HIP_OK) return rc;
+    *out_bytes = nb;
+    if (nb > out_cap || (nb && !out_host)) { (void)hipFree(d_text); return TSX_HIP_ERANGE; }
+    hipError_t e = nb ? hipMemcpy(out_host, d_text, nb, hipMemcpyDeviceToHost) : hipSuccess;
+    (void)hipFree(d_text);
+    if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return TSX_HIP_EHIP; }
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_count_fastq_bgzf_host(tsx_hip_map *m, const void *gz, size_t n) {
+    if (!m || (!gz && n)) return TSX_HIP_EINVAL;
+    if (m->p.lg != m->p.l) return TSX_HIP_EINVAL;   // see tsx_hip_count_fastq_device
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, nullptr);
+    uint8_t *d_text = nullptr;
+    size_t nb = 0;
+    int rc = inflate_bgzf_to_device((const uint8_t *)gz, n, st, &d_text, &nb);
+    if (rc != TSX_HIP_OK) return rc;
+    rc = tsx_hip_count_fastq_device(m, d_text, nb, nullptr);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(d_text);
+    if (rc == TSX_HIP_OK && e != hipSuccess) { g_last_error = hipGetErrorString(e); rc = TSX_HIP_EHIP; }
+    return rc;
 }
 
 static int ensure_staging(tsx_hip_map *m, size_t n) {

@@ -109,6 +109,12 @@ public:
 
     // countKMers body (main.cpp:104-218): whole FASTQ text -> table
     void countFastq(const char *pText, size_t iBytes) { check(tsx_hip_count_fastq_host(m_pMap, pText, iBytes)); }
+    // the same for a blocked gzip (BGZF) file image: inflated on the device (FastXReader.h:178-206 uses zlib)
+    void countFastqBgzf(const void *pGz, size_t iBytes) {
+        int rc = tsx_hip_count_fastq_bgzf_host(m_pMap, pGz, iBytes);
+        if (rc == TSX_HIP_EINVAL) throw TSXException(std::string("BGZF input: ") + tsx_hip_last_error(), rc);
+        check(rc);
+    }
 
     tsx_hip_stats stats() {
         tsx_hip_stats s;

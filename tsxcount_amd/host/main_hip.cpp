@@ -42,11 +42,31 @@ static int usage() {
     return 1;
 }
 
-// whole input in memory: plain files are mmap'ed, .gz goes through zlib
-// (FastXReader.h:178-206 picks zlib mode by the same suffix test)
-static bool load_input(const std::string &path, std::vector<char> &owned, const char *&text, size_t &n, void *&map) {
+// whole input in memory: plain files are mmap'ed; .gz (FastXReader.h:178-206 picks zlib mode by the same suffix
+// test): a blocked gzip file (BGZF) is mmap'ed as it is and inflated on the GPU (bgzf = true), any other gzip
+// stream goes through zlib here
+static bool load_input(const std::string &path, std::vector<char> &owned, const char *&text, size_t &n, void *&map,
+                       bool &bgzf) {
     map = nullptr;
+    bgzf = false;
     if (path.size() > 3 && path.rfind(".gz") == path.size() - 3) {
+        int zfd = open(path.c_str(), O_RDONLY);
+        struct stat zst;
+        if (zfd >= 0 && fstat(zfd, &zst) == 0 && zst.st_size > 0) {
+            void *zm = mmap(nullptr, (size_t)zst.st_size, PROT_READ, MAP_PRIVATE, zfd, 0);
+            if (zm != MAP_FAILED) {
+                size_t members = 0, tb = 0;
+                if (tsx_hip_bgzf_index_host(zm, (size_t)zst.st_size, &members, &tb) == TSX_HIP_OK) {
+                    close(zfd);
+                    std::cerr << "Input is BGZF: " << members << " members, " << tb << " bytes of text, inflated on the device"
+                              << std::endl;
+                    map = zm; text = (const char *)zm; n = (size_t)zst.st_size; bgzf = true;
+                    return true;
+                }
+                munmap(zm, (size_t)zst.st_size);
+            }
+        }
+        if (zfd >= 0) close(zfd);
         gzFile f = gzopen(path.c_str(), "rb");
         if (!f) return false;
         char buf[1 << 16];
@@ -119,12 +139,14 @@ int main(int argc, char *argv[]) {
         const char *text = nullptr;
         size_t n = 0;
         void *map = nullptr;
-        if (!load_input(a.input_path, owned, text, n, map)) {
+        bool bgzf = false;
+        if (!load_input(a.input_path, owned, text, n, map, bgzf)) {
             std::cerr << "Could not read " << a.input_path << std::endl;
             return 3;
         }
         auto t0 = std::chrono::steady_clock::now();
-        oMap.countFastq(text, n);
+        if (bgzf) oMap.countFastqBgzf(text, n);
+        else oMap.countFastq(text, n);
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (map) munmap(map, n);
         tsx_hip_stats st = oMap.stats();
