@@ -99,3 +99,25 @@ def test_damaged_members_are_refused():
     m.countFastqBgzf(bytes(z))          # and the intact file still counts
     assert m.stats()["kmers_added"] > 0
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocked", [True, False])
+def test_cli_reads_gz_input(tmp_path, blocked):
+    """tsxCount --input=reads.fastq.gz --check: a BGZF file is inflated on the device, any other gzip stream by zlib on
+    the host (FastXReader.h:178-206 reads both through zlib); the counts are those of the golden fixture either way."""
+    import subprocess
+    import tsxcount_amd as T
+    golden = os.path.join(ROOT, "tests", "golden")
+    text = open(os.path.join(golden, "small_t7.1000.fastq"), "rb").read()
+    fq = tmp_path / "small_t7.1000.fastq.gz"
+    fq.write_bytes(T.bgzf_compress(text) if blocked else gzip.compress(text))
+    with gzip.open(os.path.join(golden, "small_t7.1000.fastq.14.count.gz"), "rb") as f:
+        (tmp_path / "small_t7.1000.fastq.gz.14.count").write_bytes(f.read())
+    exe = os.path.join(ROOT, "tsxcount_amd", "bin", "tsxCount")
+    p = subprocess.run([exe, "--input=%s" % fq, "--mode=HIP", "--check", "--checkabort"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, out + err
+    assert "Added a total of 194697 different kmers" in out and "total errors0" in out
+    assert ("inflated on the device" in err) == blocked
