@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tsxcount_amd as T
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-k, l, seed = 31, 28, 20261004
+k, l, seed = 31, (int(sys.argv[2]) if len(sys.argv) > 2 else 28), 20261004
 nb, nk, _ = T.synth_sizes(seed, 0, reads, k)
 buf = torch.empty(nb + 256, dtype=torch.uint8, device="cuda:0")
 torch.cuda.synchronize()
