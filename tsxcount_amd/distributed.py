@@ -281,7 +281,8 @@ class ShardedCounter:
         self.cs.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.cs):
             self.sums.zero_()
-        failure = None
+        failure = None     # seen by every rank in the same window (statuses travel with the sizes): all leave together
+        late = None        # seen by this rank only: it stays in the collectives, everyone raises after the last all-reduce
         piece_off, piece_cnt, hot_g = [], [], []
         l1_windows = bool(L.tsx_hip_shard_l1_supported(m.handle)) and os.environ.get("TSX_HIP_SHARD_L1_WINDOWS", "1") != "0"
         est_total = 0
@@ -314,10 +315,17 @@ class ShardedCounter:
                 ss = [0 if p == rank else mine[p] for p in range(world)]
                 rs = [0 if p == rank else int(mo[p, 0]) for p in range(world)]
                 n_recv = own + sum(rs)
-                if n_recv > self.part:
-                    failure = (i, [-7])   # TSX_HIP_ERANGE: ownership far more skewed than the receive buffer allows
                 part = self.recv[i * self.part:(i + 1) * self.part]
-                if world > 1 and failure is None:
+                if n_recv > self.part:
+                    # TSX_HIP_ERANGE: ownership far more skewed than the receive buffer allows.  A LOCAL failure: the
+                    # peers are about to enter the collective, so this rank takes part in it (into a scratch buffer)
+                    # and in every later one, and all ranks raise together after the step's last all-reduce.
+                    late = late or (i, [-7])
+                    if world > 1:
+                        comm.all_to_all(torch.empty((sum(rs),), dtype=torch.int64, device=self.dev),
+                                        self.send[b][:sum(ss)], rs, ss)
+                    n_recv = 0
+                elif world > 1:
                     comm.all_to_all(part[own:n_recv], self.send[b][:sum(ss)], rs, ss)
                 # hot lists: padded to the longest, gathered everywhere, owners pick theirs
                 nh = min(max(max(int(x) for x in mo[:, 2].tolist()), 0), self.HOT_CAP)
@@ -332,9 +340,9 @@ class ShardedCounter:
                     comm.all_gather(self.hot_all_c[i][:g * world], self.hot_c[b][:g])
                 self.ev_exch[b].record(self.xs)
             piece_off.append(i * self.part)
-            piece_cnt.append(n_recv if failure is None else 0)
+            piece_cnt.append(n_recv if (failure is None and late is None) else 0)
             hot_g.append(g)
-            if l1_windows and failure is None:
+            if l1_windows and failure is None and late is None:
                 # level 1 of window i as soon as its keys are here, behind the scan of window i+1 on the compute stream
                 self.cs.wait_event(self.ev_exch[b])
                 if i == 0:
@@ -342,11 +350,12 @@ class ShardedCounter:
                 rc = L.tsx_hip_shard_l1_window_device(m.handle, vp(self.recv.data_ptr() + i * self.part * 8), n_recv, i, nwin,
                                                       est_total, vp(self.sums[1:].data_ptr()), vp(self.cs.cuda_stream))
                 if rc != OK:
-                    failure = (i, [rc])
-                    break
+                    late = (i, [rc])   # local: keep taking part in the later windows' collectives (see above)
         # ---- ONE partition + build over everything this rank owns, then the hot (key, count) lists
         n_recv_total = sum(piece_cnt)
         self.cs.wait_stream(self.xs)
+        if failure is None and late is not None:
+            failure = late
         if failure is None:
             po = (ctypes.c_uint64 * len(piece_off))(*piece_off)
             pc = (ctypes.c_uint64 * len(piece_cnt))(*piece_cnt)
