@@ -340,16 +340,18 @@ def test_fused_scan_sub_list_overflow(T, monkeypatch):
     st = assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
     assert st["fallback_inserts"] > 1000
     assert_same_as_oracle(T, text, 20, 24, 4, path="partitioned")
+    monkeypatch.setenv("TSX_HIP_FUSE", "1")      # the one-kernel form (scan_part_kernel), sub-lists overflowing as well
+    assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
     monkeypatch.delenv("TSX_HIP_CAP1")
     monkeypatch.setenv("TSX_HIP_FUSE", "0")
     assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
     monkeypatch.delenv("TSX_HIP_FUSE")
 
 
-@pytest.mark.parametrize("fuse", ["1", "0"])
+@pytest.mark.parametrize("fuse", ["2", "1", "0"])
 def test_fused_and_unfused_scan_agree_entry_for_entry(T, monkeypatch, fuse):
-    """Two radix levels, pieces of the host entry point (segments rebuilt from their previous content), FASTA
-    records: both forms of the scan must leave the same table."""
+    """Two radix levels, pieces of the host entry point (segments rebuilt from their previous content): the three
+    forms of the scan (2: strip descriptions + walk, 1: one fused kernel, 0: key log + level 1) leave the same table."""
     from tsxcount_amd import synth
     monkeypatch.setenv("TSX_HIP_FUSE", fuse)
     monkeypatch.setenv("TSX_HIP_PIECE_BYTES", "300000")

@@ -620,6 +620,115 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
     for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
 }
 
+// ---- the scan in two kernels: describe the strips, then walk them ------------------------------------------
+// Lines of a read file are about as long as a wave's share of a tile (1 KiB), so nearly every wave of
+// scan_log_kernel / scan_part_kernel holds some sequence bytes and walks its 16 positions with half of its lanes
+// in '+'/quality lines: the roll and append instructions -- two thirds of those kernels -- run at 50 % lane use.
+// strip_desc_kernel does the tile front end only (classify, line index, validity mask) and writes a 16-byte
+// DESCRIPTION of every strip that holds a k-mer start -- the 48 bases from its first position as 2-bit codes and
+// the 16 validity bits -- to its wave's region of a descriptor array; walk_part_kernel (tsx_partition.h) reads
+// descriptions, one per lane, every lane busy, and does first window + rolls + level-1 rings.  k <= 32.
+__global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
+                                                           int head_open, const uint32_t *tile_line, uint64_t ntiles,
+                                                           uint4 *desc, uint64_t desc_cap, unsigned long long *desc_cnt) {
+    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
+    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
+    __shared__ uint64_t s_le[TILE / 64];
+    __shared__ uint8_t s_lb[TILE / 16];
+    __shared__ uint32_t s_wsum[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
+    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
+    unsigned long long added = 0;
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t region = blockIdx.x * (NT / 64) + wave;
+    uint4 *my = desc + (uint64_t)region * desc_cap;
+    uint32_t fill = 0;  // wave-uniform
+    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
+    const uint64_t lt = (1ULL << lane) - 1ULL;
+
+    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
+    bool cur_pnl = true;
+    uint32_t cur_line = 0;
+    if ((uint64_t)blockIdx.x < ntiles) {
+        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
+        cur_line = tile_line[blockIdx.x];
+        cur = load16(buf, off, n);
+        cur_pnl = prev_is_nl(buf, off, n, head_open);
+        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
+    }
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * TILE;
+        lds_barrier();  // previous tile's LDS fully consumed
+        {
+            uint32_t nl, le, code;
+            classify16(cur, cur_pnl, nl, le, code);
+            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
+            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
+            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
+            if (tid < HALO / 16) {
+                uint32_t hnl, hle, hcode;
+                classify16(hcur, false, hnl, hle, hcode);
+                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
+                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
+            }
+            const uint32_t c = __popc(le);
+            const uint32_t inc = wave_incl_scan(c);
+            if (lane == 63) s_wsum[wave] = inc;
+            lds_barrier();
+            uint32_t woff = cur_line;
+            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        {
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
+                cur_line = tile_line[nt];
+                cur = load16(buf, off, n);
+                cur_pnl = prev_is_nl(buf, off, n, head_open);
+                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
+            }
+        }
+        lds_barrier();
+        // ---- this lane's strip: start positions s .. s+15 of the tile (as in scan_log_kernel) -----------
+        const uint32_t s0 = (uint32_t)tid * 16;
+        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
+        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
+        uint64_t m;
+        {
+            const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
+            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2];
+            m = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
+        }
+        uint64_t r = m;
+        uint32_t span = 1;
+        while (span * 2 <= k) { r |= r >> span; span *= 2; }
+        if (span < k) r |= r >> (k - span);
+        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
+        const uint32_t lb = s_lb[tid];
+        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
+        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
+        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
+        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);
+        const uint64_t g0 = base + s0;
+        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
+        const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;
+        const uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);
+        added += (unsigned long long)__popc(vm);
+        const unsigned long long hb = __ballot(vm != 0u);
+        if (hb) {
+            if (vm) my[fill + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm);
+            fill += (uint32_t)__builtin_popcountll(hb);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if (lane == 0) {
+        if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        desc_cnt[region] = fill;
+    }
+}
+
 // Records of the partitioned path are RW 64-bit words: the WK limbs of the hashed key, padded to a power of
 // two so that 128-byte bursts hold whole records (k = 65..96: three limbs travel as four words).
 template <int WK> struct RecWords { static constexpr int value = (WK == 3) ? 4 : WK; };

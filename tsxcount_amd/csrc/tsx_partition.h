@@ -731,6 +731,274 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
     }
 }
 
+// ---- walk_part_kernel: the second half of the two-kernel scan (strip_desc_kernel, tsx_kernels.h) -----------
+// Reads strip descriptions (48 bases as 2-bit codes + 16 validity bits), ONE PER LANE, every lane busy: first
+// window by the 4-bit-group LUT, 15 rolls, the keys into the level-1 rings, bursts to the workgroup's sub-lists --
+// the walk and ring parts of scan_part_kernel without its tile front end.  A batch = 512 strips = up to 8192 keys:
+// four flushes per batch (one per four positions), the same keys per flush as scan_part_kernel.  Workgroup g takes
+// the descriptor regions g, g + G, ... (a region = what one wave of strip_desc_kernel wrote).
+__global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
+                                                            const unsigned long long *desc_cnt, uint32_t nregions, int dbg,
+                                                            uint64_t *dst, uint64_t dst_cap, unsigned long long *dst_cnt,
+                                                            uint32_t nb, uint32_t shift, uint64_t *ovq_all,
+                                                            uint32_t *ovq_cnt, uint32_t ovq_cap) {
+    constexpr int HOT_N = 8;
+    __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
+    __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
+    __shared__ uint64_t s_roll[64];
+    __shared__ uint64_t s_lut4[256];
+    __shared__ uint64_t s_homh[4];
+    __shared__ uint32_t s_njobs[2];
+    __shared__ uint32_t s_ovn;
+    __shared__ uint64_t s_ovk[OVF_N];
+    __shared__ uint32_t s_ovc[OVF_N];
+    extern __shared__ uint64_t s_part[];   // rings | flush descriptors | tail and head of every ring | cursors | jobs
+    constexpr uint32_t CAP = 1u << SP_CAPBITS, cmask = CAP - 1;
+    uint64_t *s_stage = s_part;
+    unsigned long long *s_meta = reinterpret_cast<unsigned long long *>(s_part + ((size_t)nb << SP_CAPBITS));
+    unsigned long long *s_th = s_meta + nb;
+    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_th + nb);
+    uint32_t *s_job = s_cur + nb;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = gridDim.x, wg = blockIdx.x;
+    const uint32_t cap32 = (uint32_t)min(dst_cap, (uint64_t)0xFFFFFFF0u);
+    auto word_of = [&](uint32_t b, uint32_t at) -> uint64_t * { return dst + ((uint64_t)(b * G + wg) * (uint64_t)cap32 + at); };
+    if (tid < 64) s_roll[tid] = p.roll[tid];
+    if (tid < 256) s_lut4[tid] = p.roll[64 + tid];
+    if (tid < 4) {
+        const uint64_t x = (0x5555555555555555ULL * (uint64_t)tid) & p.top_mask;
+        uint64_t hh = 0;
+        for (int grp = 0; grp < 16; ++grp) hh ^= p.roll[64 + grp * 16 + ((x >> (4 * grp)) & 15u)];
+        s_homh[tid] = hh;
+    }
+    if (tid < (SP_NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
+    if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
+    if (tid < 2) s_njobs[tid] = 0;
+    if (tid == 0) s_ovn = 0;
+    for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_th[b] = 0; }
+    uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
+    unsigned long long added = 0;   // (k-mers are counted by strip_desc_kernel)
+    uint32_t spilled = 0;
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t ngrp = (2u * k + 3u) / 4u;
+
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    auto side_insert = [&](uint64_t hkey, uint64_t d) {
+        if (dbg & 1) return;
+        defer_append1(pk, hkey, d);
+    };
+    // a key that found its sub-list full: spill cache (a hot key hits it), overflow queue, deferred list
+    auto spill = [&](uint64_t key) {
+        ++spilled;
+        const uint64_t kk = key ^ OVF_SALT;
+        if (kk != 0) {
+            const uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot]), 0ULL,
+                                                     (unsigned long long)kk);
+            if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
+        }
+        if (ovq) {
+            const uint32_t at = atomicAdd(&s_ovn, 1u);
+            if (at < ovq_cap) { ovq[at] = key; return; }
+        }
+        side_insert(key, 1);
+    };
+    uint32_t round = 0;
+    // partition_ring_kernel's flush for one-word records and fixed-capacity lists: (A) one thread per list decides
+    // how many words leave (whole 128-B lines of the destination, or everything at the end), (B) an octet of lanes
+    // per list copies them.
+    auto flush = [&](bool all) {
+        const uint32_t par = round & 1u;
+        ++round;
+        if (tid == 0) s_njobs[par ^ 1u] = 0;
+        for (uint32_t b = tid; b < nb; b += SP_NT) {
+            const unsigned long long th = s_th[b];
+            const uint32_t head = (uint32_t)(th >> 32);
+            const uint32_t tail = min((uint32_t)th, head + CAP);   // arrivals past the ring went out directly
+            const uint32_t avail = tail - head;
+            const uint32_t at = s_cur[b];
+            const uint32_t end = (at + avail) & ~(uint32_t)(PART_FLUSH - 1);
+            const uint32_t nout = all ? avail : (end > at ? end - at : 0u);
+            s_meta[b] = ((unsigned long long)at << 16) | ((unsigned long long)(head & cmask) << 8) | nout;
+            s_th[b] = ((unsigned long long)(head + nout) << 32) | tail;
+            s_cur[b] = at + nout;
+            if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;
+        }
+        lds_barrier();
+        const uint32_t oct = tid >> 3, ol = tid & 7;
+        const uint32_t njobs = s_njobs[par];
+        // about 45 % of the lists have a line to send after a half strip: two jobs per octet and pass
+        constexpr int ITER = 2;
+        for (uint32_t j0 = 0; j0 < njobs; j0 += ITER * (SP_NT / 8)) {
+            unsigned long long meta[ITER];
+            uint32_t bj[ITER];
+            uint64_t k0[ITER], k1[ITER];
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t j = j0 + oct + u * (SP_NT / 8);
+                bj[u] = (j < njobs) ? s_job[j] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t j = j0 + oct + u * (SP_NT / 8);
+                meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
+            }
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
+                const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
+                k0[u] = (ol < nout) ? ring[((hd + ol) ^ bj[u]) & cmask] : 0;     // (place ^ list: see the append)
+                k1[u] = (ol + 8 < nout) ? ring[((hd + ol + 8) ^ bj[u]) & cmask] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < ITER; ++u) {
+                const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
+                const uint32_t at = (uint32_t)(meta[u] >> 16);
+                const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
+                uint64_t *out = word_of(bj[u], at);
+                if (ol < nout) { if (at + ol < cap32) out[ol] = k0[u]; else spill(k0[u]); }
+                if (ol + 8 < nout) { if (at + ol + 8 < cap32) out[ol + 8] = k1[u]; else spill(k1[u]); }
+                if (nout > 16)
+                    for (uint32_t q = ol + 16; q < nout; q += 8) {
+                        const uint64_t w = ring[((hd + q) ^ bj[u]) & cmask];
+                        if (at + q < cap32) out[q] = w; else spill(w);
+                    }
+            }
+        }
+    };
+
+    lds_barrier();
+    for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+        const uint32_t nr = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
+        const uint4 *rd = desc + (uint64_t)r * desc_cap;
+        uint4 dn = (tid < nr) ? rd[tid] : make_uint4(0, 0, 0, 0);
+        for (uint32_t base = 0; base < nr; base += SP_NT) {
+            const uint4 d = dn;
+            if (base + SP_NT < nr) dn = (base + SP_NT + tid < nr) ? rd[base + SP_NT + tid] : make_uint4(0, 0, 0, 0);   // next batch
+            const uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+            const bool wave_has = __ballot(vm != 0u) != 0ULL;   // only the last batch of a region has idle waves
+            uint64_t h = 0;
+            uint32_t inc = 0, single = 0;
+            if (wave_has) {
+                const uint64_t lo = (uint64_t)cw0 | ((uint64_t)cw1 << 32), hi = cw2;
+                if (vm) {
+                    const uint64_t x = lo & p.top_mask;
+                    for (uint32_t grp = 0; grp < ngrp; ++grp) h ^= s_lut4[grp * 16u + ((uint32_t)(x >> (4u * grp)) & 15u)];
+                }
+                {
+                    const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
+                    const uint32_t w0 = (ws == 0u) ? cw0 : (ws == 1u) ? cw1 : cw2;
+                    const uint32_t w1 = (ws == 0u) ? cw1 : (ws == 1u) ? cw2 : 0u;
+                    inc = __funnelshift_r(w0, w1, sh);
+                }
+            uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
+            {
+                const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
+                uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
+                uint32_t span = 1;
+                while (span * 2 <= k - 1) {
+                    const uint32_t sh = 2u * span;
+                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                    rhi |= rhi >> sh;
+                    span *= 2;
+                }
+                if (span < k - 1) {
+                    const uint32_t sh = 2u * (k - 1 - span);
+                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                }
+                uint32_t x = ~(uint32_t)rlo & 0x55555555u;
+                x = (x | (x >> 1)) & 0x33333333u;
+                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                x = (x | (x >> 4)) & 0x00FF00FFu;
+                homm = (x | (x >> 8)) & 0xFFFFu;
+            }
+            const uint32_t hv = vm & homm;
+            single = vm & ~homm;
+            if (__ballot(hv != 0u)) {
+                for (uint32_t b = 0; b < 4; ++b) {
+                    uint32_t e = cw0 ^ (0x55555555u * b);
+                    uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
+                    y = (y | (y >> 1)) & 0x33333333u;
+                    y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+                    y = (y | (y >> 4)) & 0x00FF00FFu;
+                    y = (y | (y >> 8)) & 0xFFFFu;
+                    uint32_t tot = (uint32_t)__popc(hv & y);
+                    if (__ballot(tot != 0u) == 0ULL) continue;
+                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                    if (lane == 0) {
+                        const uint64_t key = s_homh[b];
+                        uint64_t *hkey = s_hot_key + wave * HOT_N;
+                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                        int at = -1;
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (hcnt[q] && hkey[q] == key) { at = q; break; }
+                        if (at < 0)
+                            for (int q = 0; q < HOT_N; ++q)
+                                if (!hcnt[q]) { at = q; hkey[q] = key; break; }
+                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                        else side_insert(key, tot);
+                    }
+                }
+            }
+        }
+            // ---- the strip in four quarters of 4 positions: roll, append to the rings, flush ----------------------
+            for (uint32_t j0 = 0; j0 < 16; j0 += 4) {
+                const uint32_t s4 = (single >> j0) & 0xFu;
+                if (wave_has) {
+                    uint64_t hs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hs[j] = h;
+                        if (j0 + j < 15) {
+                            const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
+                                                 (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
+                            h = (h >> 2) ^ s_roll[idx];
+                        }
+                    }
+                    if (__ballot(s4 != 0u) != 0ULL) {
+                        uint32_t bq[4];
+                        unsigned long long sl[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bq[j] = (uint32_t)(hs[j] >> shift) & (nb - 1);
+                            sl[j] = ((s4 >> j) & 1u) ? atomicAdd(&s_th[bq[j]], 1ULL) : 0ULL;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if ((s4 >> j) & 1u) {
+                                const uint32_t b = bq[j];
+                                if ((uint32_t)sl[j] - (uint32_t)(sl[j] >> 32) < CAP) {
+                                    s_stage[(b << SP_CAPBITS) + (((uint32_t)sl[j] ^ b) & cmask)] = hs[j];
+                                } else {   // ring full: the next place of the list directly
+                                    const uint32_t at = atomicAdd(&s_cur[b], 1u);
+                                    if (at < cap32) *word_of(b, at) = hs[j];
+                                    else spill(hs[j]);
+                                }
+                            }
+                        }
+                    }
+                }
+                lds_barrier();
+                flush(false);
+                lds_barrier();
+            }
+        }
+    }
+    lds_barrier();
+    flush(true);
+    lds_barrier();
+    for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * G + wg] = min(s_cur[b], cap32);
+    if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) side_insert(s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
+    if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
+    if (tid < (SP_NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    for (int d = 32; d > 0; d >>= 1) { added += __shfl_down(added, d, 64); spilled += __shfl_down(spilled, d, 64); }
+    if (lane == 0) {
+        if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        if (spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
+    }
+}
+
 // Inserts the overflow queues partition_ring_kernel left behind (one queue of `cap` records per
 // workgroup) -- after the segment build, like every insert that goes to the table directly.
 template <int WK>

@@ -755,6 +755,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         m->attr_done = true;
@@ -971,11 +972,20 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const int greg = gs * (NT / 64);
     PartPlan pl;
     // scan fused with radix level 1 (TSX_HIP_FUSE=0: the key log + separate level 1): local runs, one-limb keys
-    const char *fuse_env = getenv("TSX_HIP_FUSE");   // read per call: the tests run both forms in one process
-    const int fuse = fuse_env ? atoi(fuse_env) : 1;
+    // 2 (default): strip descriptions + walk (two kernels), 1: scan_part_kernel (one), 0: key log + separate level 1.
+    // Read per call: the tests run all forms in one process.
+    const char *fuse_env = getenv("TSX_HIP_FUSE");
+    const int fuse = fuse_env ? atoi(fuse_env) : 2;
     const uint64_t ntiles_sp = (own_end + SP_TILE - 1) / SP_TILE;
     const int g_sp = (int)std::min<uint64_t>(ntiles_sp, (uint64_t)m->cus * 2);
-    int rc = plan_partition(m, maxrec, greg, true, shard_send ? nown : 0, st, pl, (fuse && !shard_send && p.wk == 1) ? g_sp : 0);
+    // strip_desc_kernel: 52 VGPRs, 2.4 KiB of LDS -- eight workgroups per CU (five: 3.9 ms for both kernels, eight: 3.7)
+    static const int desc_wgs = getenv("TSX_HIP_DESC_WGS") ? std::min(16, std::max(1, atoi(getenv("TSX_HIP_DESC_WGS")))) : 8;
+    const int gd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * desc_wgs), gdreg = gd * (NT / 64);
+    const bool want_fuse = fuse && !shard_send && p.wk == 1;
+    int rc = plan_partition(m, maxrec, (want_fuse && fuse == 2) ? std::max(greg, gdreg) : greg, true, shard_send ? nown : 0, st,
+                            pl, want_fuse ? g_sp : 0);
+    if (rc == TSX_HIP_OK && want_fuse && !pl.fused)   // a one-level table: the key log form, planned for its own regions
+        rc = plan_partition(m, maxrec, greg, true, 0, st, pl, 0);
     if (rc != TSX_HIP_OK) return rc;
     // what cannot take the fast route: the caller's hot list (sharded scan), else the map's deferred list
     TableParams pp = m->p;
@@ -994,9 +1004,23 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
         if (rc != TSX_HIP_OK) return rc;
         const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);   // ring, flush descriptor, tail|head, cursor, job
-        hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
-                           (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
-                           (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
+        if (fuse == 2) {
+            // two kernels: strip descriptions (16 B per strip with a k-mer start, one region per wave, in buffer 0 --
+            // level 2 overwrites it later), then the walk with every lane busy
+            const uint64_t desc_cap = ((ntiles + gd - 1) / gd) * 64;
+            rc = grow(st, m->d_buf[0], m->buf_bytes[0], (size_t)gdreg * desc_cap * 16);
+            if (rc != TSX_HIP_OK) return rc;
+            hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
+                               (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(walk_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
+                               (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                               (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
+        } else {
+            hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
+                               (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                               (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
+        }
     } else if (p.wk == 1) {
         hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
