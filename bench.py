@@ -299,7 +299,9 @@ def main():
                        "build": rec_b * keys_logged + table_bytes}
         # scan fused with radix level 1 (scan_part_kernel): there is no level-1 launch, its stage time is ~0
         fused = partitioned and m.wk == 1 and stage["level1"] / pieces < 0.05
-        names = {"scan": (("scan_part_kernel" if fused else "scan_log_kernel") if m.wk == 1
+        two = os.environ.get("TSX_HIP_FUSE", "2") == "2"   # the scan in two kernels (default): one stage here
+        names = {"scan": ((("strip_desc_kernel + walk_part_kernel" if two else "scan_part_kernel") if fused
+                           else "scan_log_kernel") if m.wk == 1
                           else "scan_log_wide_kernel<%d>" % m.wk) if partitioned
                  else "count_fastq_kernel<%d>" % m.wk,
                  "level1": "partition_ring_kernel (level 1)", "level2": "partition_ring_kernel (level 2)",

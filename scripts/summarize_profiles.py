@@ -65,11 +65,14 @@ for k, v in agg.items():
         tot_r += rd
         tot_w += wr
 # the scan kernel: fused with radix level 1 (scan_part_kernel) where the run used it
-SCAN = "tsx::scan_part_kernel" if "tsx::scan_part_kernel" in part["kernels"] else "tsx::scan_log_kernel"
-FUSED = SCAN == "tsx::scan_part_kernel"
+# (or split in two: strip_desc_kernel + walk_part_kernel -- the scan stage is then both)
+TWO = "tsx::walk_part_kernel" in part["kernels"]
+SCAN = "tsx::walk_part_kernel" if TWO else ("tsx::scan_part_kernel" if "tsx::scan_part_kernel" in part["kernels"] else "tsx::scan_log_kernel")
+FUSED = SCAN != "tsx::scan_log_kernel"
 scan = part["kernels"].get(SCAN, {})
 part["kernel"] = SCAN
 part["hbm_bytes_per_launch"] = scan.get("hbm_read_bytes", 0) + scan.get("hbm_write_bytes", 0)
+# the kernel a step spends most time in is the segment build since the scan was split (bench.py: roofline.kernel)
 # bench.py stages: the partition kernel runs twice per step (level 1, then level 2), told apart by dispatch order
 def nth_dispatch_bytes(kernel, nth):
     v = per_dispatch.get(kernel, {})
@@ -80,7 +83,10 @@ def nth_dispatch_bytes(kernel, nth):
     if nth >= len(rd) or nth >= len(wr):
         return None
     return rd[nth] * 2048 + wr[nth] * 1024
-part["stages"] = {"scan": nth_dispatch_bytes(SCAN, 0),
+def plus(a, b):
+    return None if a is None or b is None else a + b
+part["stages"] = {"scan": plus(nth_dispatch_bytes(SCAN, 0), nth_dispatch_bytes("tsx::strip_desc_kernel", 0)) if TWO
+                          else nth_dispatch_bytes(SCAN, 0),
                   "level1": None if FUSED else nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0),
                   "level2": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0 if FUSED else 1),
                   "build": nth_dispatch_bytes(BUILD, 0)}
