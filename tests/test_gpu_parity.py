@@ -507,6 +507,7 @@ def test_fuzzed_record_structure_both_paths(T, seed):
 
 
 @pytest.mark.parametrize("k,l,path", [(21, 16, "atomic"), (21, 16, "partitioned"), (31, 20, "partitioned"),
+                                      (31, 23, "partitioned"), (20, 24, "partitioned"),   # two radix levels: strip_desc + walk_part
                                       (63, 18, "partitioned"), (127, 18, "atomic"), (127, 18, "partitioned")])
 def test_fasta_records(T, k, l, path):
     """tsx_hip_set_record_lines(2): FASTA as FASTXreader<FASTAEntry> reads it (FastXReader.h:97-116) -- header
@@ -602,7 +603,7 @@ def test_device_entry_point_windows(T):
     code = ("import sys; sys.path.insert(0, %r); import numpy as np, torch; import tsxcount_amd as T;"
             "from tsxcount_amd import synth; text = synth.fastq(14, 0, 500);"
             "buf = torch.frombuffer(bytearray(text), dtype=torch.uint8).to('cuda:0');"
-            "m = T.TSXHashMapHIP(20, 0, 31); m.set_path(sys.argv[2]); torch.cuda.synchronize();"
+            "m = T.TSXHashMapHIP(int(sys.argv[3]), 0, 31); m.set_path(sys.argv[2]); torch.cuda.synchronize();"
             "m.countFastqDevice(buf.data_ptr(), len(text)); m.sync(); k, c = m.getAllKmers();"
             "o = np.lexsort(k.T[::-1]); np.save(sys.argv[1], np.concatenate([k[o].ravel(), c[o]]))" % ROOT)
     from tsxcount_amd import synth
@@ -612,11 +613,13 @@ def test_device_entry_point_windows(T):
     kmers, counts = o.dump()
     b = np.lexsort(kmers.T[::-1])
     expect = np.concatenate([kmers[b].ravel(), counts[b]])
-    for window, path in (("4096", "atomic"), ("100000", "partitioned"), ("65536", "atomic")):
+    # l = 23: a table split by two radix levels -- the windows then go through strip_desc_kernel + walk_part_kernel
+    for window, path, l in (("4096", "atomic", 20), ("100000", "partitioned", 20), ("65536", "atomic", 20),
+                            ("40000", "partitioned", 23), ("8192", "partitioned", 23)):
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "r.npy")
             env = dict(os.environ, TSX_HIP_DEV_WINDOW=window)
-            subprocess.run([sys.executable, "-c", code, f, path], check=True, env=env, timeout=300)
+            subprocess.run([sys.executable, "-c", code, f, path, str(l)], check=True, env=env, timeout=300)
             assert np.array_equal(np.load(f), expect), (window, path)
 
 
