@@ -729,6 +729,187 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
     }
 }
 
+// walk_log_kernel: scan_log_kernel's walk fed from strip descriptions (strip_desc_kernel above) instead of its own
+// tile front end -- one description per lane, every lane busy, no barrier after the set-up (a wave reads descriptor
+// regions w, w + G, ... and appends to its own log region; the histogram is the wave's).  Used where the keys must
+// come out as a packed log: sharded scans (histogram by owner) and tables that need one radix level.
+__global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
+                                                         const unsigned long long *desc_cnt, uint32_t nregions, int dbg,
+                                                         uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt,
+                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift) {
+    constexpr int HOT_N = 8;
+    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hist[(NT / 64) * 512];  // fan-out <= 512
+    __shared__ uint64_t s_roll[64];
+    __shared__ uint64_t s_homh[4];
+    extern __shared__ uint64_t s_lut[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lut_words = p.groups * (1 << p.g);
+    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
+    for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
+    if (tid < 64) s_roll[tid] = p.roll[tid];
+    if (tid < 4) {
+        const uint64_t x[1] = {(0x5555555555555555ULL * (uint64_t)tid) & p.top_mask};
+        uint64_t hh[1];
+        hash_apply<1>(p, p.lut, x, hh);
+        s_homh[tid] = hh[0];
+    }
+    if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
+    uint64_t *my_log = log + (uint64_t)region * log_cap;
+    uint32_t *my_hist = s_hist + wave * 512;
+    uint32_t fill = 0;  // wave-uniform
+    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    auto side_insert = [&](uint64_t hkey, uint64_t d) {
+        if (dbg & 1) return;
+        defer_append1(pk, hkey, d);
+    };
+    lds_barrier();
+    for (uint32_t r = region; r < nregions; r += G) {
+        const uint32_t nr = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
+        const uint4 *rd = desc + (uint64_t)r * desc_cap;
+        uint4 dn = ((uint32_t)lane < nr) ? rd[lane] : make_uint4(0, 0, 0, 0);
+        for (uint32_t base = 0; base < nr; base += 64u) {
+            const uint4 d = dn;
+            if (base + 64u < nr) dn = (base + 64u + (uint32_t)lane < nr) ? rd[base + 64u + lane] : make_uint4(0, 0, 0, 0);
+            const uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+            uint64_t h = 0;
+            if (vm) {
+                const uint64_t x[1] = {((uint64_t)cw0 | ((uint64_t)cw1 << 32)) & p.top_mask};
+                uint64_t hh[1];
+                hash_apply<1>(p, (const uint64_t *)s_lut, x, hh);
+                h = hh[0];
+            }
+            uint32_t inc;
+            {
+                const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
+                const uint32_t w0 = (ws == 0u) ? cw0 : (ws == 1u) ? cw1 : cw2;
+                const uint32_t w1 = (ws == 0u) ? cw1 : (ws == 1u) ? cw2 : 0u;
+                inc = __funnelshift_r(w0, w1, sh);
+            }
+            uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
+            {
+                const uint64_t lo = (uint64_t)cw0 | ((uint64_t)cw1 << 32), hi = cw2;
+                const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
+                uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
+                uint32_t span = 1;   // bases covered by the smear so far; k - 1 adjacent pairs must agree
+                while (span * 2 <= k - 1) {
+                    const uint32_t sh = 2u * span;
+                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                    rhi |= rhi >> sh;
+                    span *= 2;
+                }
+                if (span < k - 1) {
+                    const uint32_t sh = 2u * (k - 1 - span);
+                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
+                }
+                uint32_t x = ~(uint32_t)rlo & 0x55555555u;   // even bits -> 16 contiguous bits
+                x = (x | (x >> 1)) & 0x33333333u;
+                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                x = (x | (x >> 4)) & 0x00FF00FFu;
+                homm = (x | (x >> 8)) & 0xFFFFu;
+            }
+            const uint32_t hv = vm & homm;
+            const uint32_t single = vm & ~homm;
+            if (__ballot(hv != 0u)) {
+                for (uint32_t b = 0; b < 4; ++b) {   // which of the four: the base at the position
+                    uint32_t e = cw0 ^ (0x55555555u * b);
+                    uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
+                    y = (y | (y >> 1)) & 0x33333333u;
+                    y = (y | (y >> 2)) & 0x0F0F0F0Fu;
+                    y = (y | (y >> 4)) & 0x00FF00FFu;
+                    y = (y | (y >> 8)) & 0xFFFFu;
+                    uint32_t tot = (uint32_t)__popc(hv & y);
+                    if (__ballot(tot != 0u) == 0ULL) continue;
+                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                    if (lane == 0) {
+                        const uint64_t key = s_homh[b];
+                        uint64_t *hkey = s_hot_key + wave * HOT_N;
+                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                        int at = -1;
+                        for (int q = 0; q < HOT_N; ++q)
+                            if (hcnt[q] && hkey[q] == key) { at = q; break; }
+                        if (at < 0)
+                            for (int q = 0; q < HOT_N; ++q)
+                                if (!hcnt[q]) { at = q; hkey[q] = key; break; }
+                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                        else side_insert(key, tot);
+                    }
+                }
+            }
+            // The strip is walked in two halves of 8 positions (the hash rolls on across them): pass A
+            // rolls and keeps the 8 hashes, pass B appends them to this wave's log region, one contiguous
+            // piece per position.
+            for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
+                const uint32_t s8 = (single >> j0) & 0xFFu;
+                if (__ballot(s8 != 0u) == 0ULL) {   // nothing to log in this half: only roll on
+                    if (j0 == 0) {
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
+                                                 (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
+                            h = (h >> 2) ^ s_roll[idx];
+                        }
+                    }
+                    continue;
+                }
+                uint64_t hs[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    hs[j] = h;
+                    if (j0 + j < 15) {
+                        const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
+                                             (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
+                        h = (h >> 2) ^ s_roll[idx];
+                    }
+                }
+                if (fill + 64u * 8u <= cap32) {   // the usual case: the region has room for whatever this half logs
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool em = (s8 >> j) & 1u;
+                        const unsigned long long mk = __ballot(em);
+                        if (mk) {
+                            if (em) {
+                                const uint64_t key = hs[j];
+                                my_log[fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = key;
+                                atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
+                            }
+                            fill += (uint32_t)__builtin_popcountll(mk);
+                        }
+                    }
+                } else {
+                    for (int j = 0; j < 8; ++j) {
+                        const bool em = (s8 >> j) & 1u;
+                        const unsigned long long mk = __ballot(em);
+                        if (mk) {
+                            if (em) {
+                                uint64_t key = hs[0];
+    #pragma unroll
+                                for (int t = 1; t < 8; ++t) key = (j == t) ? hs[t] : key;
+                                const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
+                                if (at < cap32) {
+                                    my_log[at] = key;
+                                    atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
+                                } else {
+                                    side_insert(key, 1);  // region full: deferred list (or the exchanged hot list)
+                                }
+                            }
+                            fill += (uint32_t)__builtin_popcountll(mk);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    if (lane == 0) log_cnt[region] = min(fill, cap32);   // (k-mers are counted by strip_desc_kernel)
+    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
+}
+
 // Records of the partitioned path are RW 64-bit words: the WK limbs of the hashed key, padded to a power of
 // two so that 128-byte bursts hold whole records (k = 65..96: three limbs travel as four words).
 template <int WK> struct RecWords { static constexpr int value = (WK == 3) ? 4 : WK; };

@@ -94,6 +94,8 @@ struct tsx_hip_map {
     std::vector<unsigned long long> h_regions;   // host copy of the region table of a sharded build (starts, then sizes)
     PartPlan *sh_pl = nullptr;                   // sharded run, level 1 per exchange window: the plan made at window 0,
     uint32_t sh_rw = 0, sh_windows = 0;          // regions per window, windows of the step,
+    unsigned long long *d_desc_cnt = nullptr;    // strips described per wave of strip_desc_kernel (key log form)
+    size_t desc_cnt_entries = 0;
     uint64_t *sh_buf1 = nullptr;                 // and its own sub-list buffer and counters (the scans of the later
     size_t sh_buf1_bytes = 0;                    // windows plan with -- and clear -- the map's while level 1 of the
     unsigned long long *sh_cnt = nullptr;        // earlier ones has already left its sizes there)
@@ -520,7 +522,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
     drop_sh_plan(m);
-    (void)hipFree(m->sh_buf1); (void)hipFree(m->sh_cnt);
+    (void)hipFree(m->sh_buf1); (void)hipFree(m->sh_cnt); (void)hipFree(m->d_desc_cnt);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
     (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt); (void)hipFree(m->d_small);
     (void)hipFree(m->d_def_rec); (void)hipFree(m->d_def_cnt); (void)hipFree(m->d_def_n);
@@ -982,6 +984,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     static const int desc_wgs = getenv("TSX_HIP_DESC_WGS") ? std::min(16, std::max(1, atoi(getenv("TSX_HIP_DESC_WGS")))) : 8;
     const int gd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * desc_wgs), gdreg = gd * (NT / 64);
     const bool want_fuse = fuse && !shard_send && p.wk == 1;
+    const char *scan2_env = getenv("TSX_HIP_SCAN2");   // 0: scan_log_kernel (one kernel) where the keys go to a log
+    const bool scan2 = !scan2_env || atoi(scan2_env) != 0;
     int rc = plan_partition(m, maxrec, (want_fuse && fuse == 2) ? std::max(greg, gdreg) : greg, true, shard_send ? nown : 0, st,
                             pl, want_fuse ? g_sp : 0);
     if (rc == TSX_HIP_OK && want_fuse && !pl.fused)   // a one-level table: the key log form, planned for its own regions
@@ -1021,6 +1025,25 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
                                (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                                (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
         }
+    } else if (p.wk == 1 && scan2) {
+        // key log form (sharded scans, one-level tables), the scan in two kernels as well: descriptions into buffer 1
+        // (level 1 fills it only afterwards), then the walk with every lane busy into the wave's log region
+        const uint64_t desc_cap = ((ntiles + gd - 1) / gd) * 64;
+        rc = grow(st, m->d_buf[1], m->buf_bytes[1], (size_t)gdreg * desc_cap * 16);
+        if (rc != TSX_HIP_OK) return rc;
+        pl.buf1 = m->d_buf[1];
+        {
+            size_t have = m->desc_cnt_entries;
+            rc = grow(st, m->d_desc_cnt, have, (size_t)gdreg * 8);
+            m->desc_cnt_entries = have;
+            if (rc != TSX_HIP_OK) return rc;
+        }
+        hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
+                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], desc_cap, m->d_desc_cnt);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(walk_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, (const uint4 *)m->d_buf[1], desc_cap,
+                           (const unsigned long long *)m->d_desc_cnt, (uint32_t)gdreg, m->dbg, m->d_buf[0], pl.log_cap,
+                           pl.c_log, pl.d_hist, hist_nb, hist_shift);
     } else if (p.wk == 1) {
         hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
