@@ -1158,6 +1158,283 @@ __global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, con
     for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
 }
 
+// ---- the two-kernel scan for multi-limb keys (k > 32) -------------------------------------------------------
+// As strip_desc_kernel / walk_log_kernel.  What the walk of a strip needs of the text is its FIRST k-mer (WK limbs),
+// the 16 bases that enter behind it and the validity bits (the bases that leave are the first 16 of the k-mer): a
+// description is 2 WK + 2 words, padded to whole 16-byte units.
+template <int WK> struct WideDescU4 { static constexpr int value = (2 * WK + 2 + 3) / 4; };   // uint4 per description
+
+template <int WK>
+__global__ __launch_bounds__(NT, 4) void strip_desc_wide_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
+                                                                int head_open, const uint32_t *tile_line, uint64_t ntiles,
+                                                                uint4 *desc, uint64_t desc_cap, unsigned long long *desc_cnt) {
+    constexpr int DU = WideDescU4<WK>::value;
+    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
+    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
+    __shared__ uint64_t s_le[TILE / 64];
+    __shared__ uint8_t s_lb[TILE / 16];
+    __shared__ uint32_t s_wsum[NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
+    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
+    unsigned long long added = 0;
+    const uint32_t k = (uint32_t)p.k;
+    const uint32_t region = blockIdx.x * (NT / 64) + wave;
+    uint4 *my = desc + (uint64_t)region * desc_cap * DU;
+    uint32_t fill = 0;  // wave-uniform, in descriptions
+    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
+    const uint64_t lt = (1ULL << lane) - 1ULL;
+
+    // text loaded one tile ahead, as in scan_log_kernel
+    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
+    bool cur_pnl = true;
+    uint32_t cur_line = 0;
+    if ((uint64_t)blockIdx.x < ntiles) {
+        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
+        cur_line = tile_line[blockIdx.x];
+        cur = load16(buf, off, n);
+        cur_pnl = prev_is_nl(buf, off, n, head_open);
+        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
+    }
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t base = tile * TILE;
+        lds_barrier();  // previous tile's LDS fully consumed
+        {
+            uint32_t nl, le, code;
+            classify16(cur, cur_pnl, nl, le, code);
+            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
+            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
+            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
+            if (tid < HALO / 16) {
+                uint32_t hnl, hle, hcode;
+                classify16(hcur, false, hnl, hle, hcode);
+                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
+                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
+            }
+            const uint32_t c = __popc(le);
+            const uint32_t inc = wave_incl_scan(c);
+            if (lane == 63) s_wsum[wave] = inc;
+            lds_barrier();
+            uint32_t woff = cur_line;   // lines before the tile, loaded a tile ahead like its text
+            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
+        }
+        {
+            const uint64_t nt = tile + gridDim.x;
+            if (nt < ntiles) {
+                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
+                cur_line = tile_line[nt];
+                cur = load16(buf, off, n);
+                cur_pnl = prev_is_nl(buf, off, n, head_open);
+                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
+            }
+        }
+        lds_barrier();
+
+        const uint32_t s0 = (uint32_t)tid * 16;
+        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
+        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
+        // newline flags of bytes [s0, s0 + 160): a window of position j <= 15 reaches byte s0 + 15 + k - 1 <= s0 + 141
+        uint64_t r[3];
+        {
+            const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
+            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2], a3 = nl32[w + 3], a4 = nl32[w + 4],
+                           a5 = nl32[w + 5];
+            r[0] = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
+            r[1] = (uint64_t)__funnelshift_r(a2, a3, sh) | ((uint64_t)__funnelshift_r(a3, a4, sh) << 32);
+            r[2] = (uint64_t)__funnelshift_r(a4, a5, sh);
+        }
+        {   // bad_j = a newline in [s0+j, s0+j+k): OR of the mask shifted by 0..k-1, by doubling
+            uint32_t span = 1;
+            while (span * 2 <= k) { shr_or3(r, span); span *= 2; }
+            if (span < k) shr_or3(r, k - span);
+        }
+        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
+        const uint32_t lb = s_lb[tid];
+        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
+        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
+        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
+        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
+        const uint64_t g0 = base + s0;
+        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
+        const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;   // FASTA: every second line is a sequence
+        const uint32_t vm = ~(uint32_t)r[0] & b0 & nb1 & ((1u << jmax) - 1u);   // sequence line, no newline, in range
+        added += (unsigned long long)__popc(vm);
+        const unsigned long long hb = __ballot(vm != 0u);
+        if (hb) {
+            if (vm) {
+                uint64_t x[WK];
+                extract_kmer<WK>(s_codes, s0, p.top_mask, x);
+                uint32_t inc;
+                {
+                    const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
+                    inc = __funnelshift_r(codes32[tid + ws], codes32[tid + ws + 1], sh);
+                }
+                uint32_t w[DU * 4];
+#pragma unroll
+                for (int t = 0; t < DU * 4; ++t) w[t] = 0;
+#pragma unroll
+                for (int t = 0; t < WK; ++t) { w[2 * t] = (uint32_t)x[t]; w[2 * t + 1] = (uint32_t)(x[t] >> 32); }
+                w[2 * WK] = inc;
+                w[2 * WK + 1] = vm;
+                uint4 *o = my + (uint64_t)(fill + (uint32_t)__builtin_popcountll(hb & lt)) * DU;
+#pragma unroll
+                for (int u = 0; u < DU; ++u) o[u] = make_uint4(w[4 * u], w[4 * u + 1], w[4 * u + 2], w[4 * u + 3]);
+            }
+            fill += (uint32_t)__builtin_popcountll(hb);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
+    if (lane == 0) {
+        if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        desc_cnt[region] = fill;
+    }
+}
+
+template <int WK>
+__global__ __launch_bounds__(NT, 2) void walk_log_wide_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
+                                                              const unsigned long long *desc_cnt, uint32_t nregions, int dbg,
+                                                              uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt,
+                                                              uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift) {
+    constexpr int RW = RecWords<WK>::value;
+    constexpr int DU = WideDescU4<WK>::value;
+    constexpr int HOT_N = 8;
+    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N * WK];
+    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hist[(NT / 64) * 512];
+    __shared__ uint64_t s_roll[64 * WK];
+    __shared__ uint64_t s_homh[4 * WK];
+    extern __shared__ uint64_t s_lut[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lut_words = p.groups * (1 << p.g) * WK;
+    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
+    for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
+    for (int i = tid; i < 64 * WK; i += NT) s_roll[i] = p.roll[i];
+    if (tid < 4) {
+        uint64_t x[WK], hh[WK];
+#pragma unroll
+        for (int t = 0; t < WK; ++t) x[t] = 0x5555555555555555ULL * (uint64_t)tid;
+        x[WK - 1] &= p.top_mask;
+        hash_apply<WK>(p, p.lut, x, hh);
+#pragma unroll
+        for (int t = 0; t < WK; ++t) s_homh[tid * WK + t] = hh[t];
+    }
+    if (tid < (NT / 64) * HOT_N) s_hot_cnt[tid] = 0;
+    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
+    uint64_t *my_log = log + (uint64_t)region * log_cap * RW;
+    uint32_t *my_hist = s_hist + wave * 512;
+    uint32_t fill = 0;  // wave-uniform, in records
+    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
+    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint64_t lt = (1ULL << lane) - 1ULL;
+    lds_barrier();
+    for (uint32_t r = region; r < nregions; r += G) {
+        const uint32_t nr = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
+        const uint4 *rd = desc + (uint64_t)r * desc_cap * DU;
+        for (uint32_t base = 0; base < nr; base += 64u) {
+            uint32_t w[DU * 4];
+#pragma unroll
+            for (int t = 0; t < DU * 4; ++t) w[t] = 0;
+            if (base + (uint32_t)lane < nr) {
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    const uint4 q = rd[(uint64_t)(base + lane) * DU + u];
+                    w[4 * u] = q.x; w[4 * u + 1] = q.y; w[4 * u + 2] = q.z; w[4 * u + 3] = q.w;
+                }
+            }
+            const uint32_t cw0 = w[0], inc = w[2 * WK], vm = w[2 * WK + 1];
+            uint64_t h[WK];
+#pragma unroll
+            for (int t = 0; t < WK; ++t) h[t] = 0;
+            if (vm) {
+                uint64_t x[WK];
+#pragma unroll
+                for (int t = 0; t < WK; ++t) x[t] = (uint64_t)w[2 * t] | ((uint64_t)w[2 * t + 1] << 32);
+                hash_apply<WK>(p, (const uint64_t *)s_lut, x, h);
+            }
+            uint32_t homcnt = 0;   // four 8-bit counters: homopolymer k-mers of base b seen in this strip
+            for (uint32_t j = 0; j < 16; ++j) {
+                const bool valid = (vm >> j) & 1u;
+                const uint32_t ob = __builtin_amdgcn_ubfe(cw0, 2u * j, 2u);
+                bool hom = valid && h[0] == s_homh[ob * WK];
+                if (hom) {
+    #pragma unroll
+                    for (int t = 1; t < WK; ++t) hom &= (h[t] == s_homh[ob * WK + t]);
+                }
+                homcnt += hom ? (1u << (8u * ob)) : 0u;
+                const bool em = valid && !hom;
+                const unsigned long long mk = __ballot(em);
+                if (mk) {
+                    if (em) {
+                        const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & lt);
+                        if (at < cap32) {
+                            uint64_t *o = my_log + (uint64_t)at * RW;
+    #pragma unroll
+                            for (int t = 0; t < RW; ++t) o[t] = (t < WK) ? h[t < WK ? t : 0] : 0ULL;
+                            atomicAdd(&my_hist[(uint32_t)(h[0] >> hist_shift) & (hist_nb - 1)], 1u);
+                        } else if (!(dbg & 1)) {
+                            uint64_t rec[RW];
+    #pragma unroll
+                            for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? h[t < WK ? t : 0] : 0ULL;
+                            defer_append<RW>(pk, rec, 1);   // region full
+                        }
+                    }
+                    fill += (uint32_t)__builtin_popcountll(mk);
+                }
+                if (j < 15) {
+                    const uint32_t idx = ((uint32_t)h[0] & 3u) | (ob << 2) | (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
+    #pragma unroll
+                    for (int t = 0; t < WK; ++t) {
+                        uint64_t v = h[t] >> 2;
+                        if (t + 1 < WK) v |= h[t + 1] << 62;
+                        h[t] = v ^ s_roll[idx * WK + t];
+                    }
+                }
+            }
+            if (__ballot(homcnt != 0u)) {
+                for (uint32_t b = 0; b < 4; ++b) {
+                    uint32_t tot = (homcnt >> (8u * b)) & 0xFFu;
+                    if (__ballot(tot != 0u) == 0ULL) continue;
+                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+                    if (lane == 0) {
+                        uint64_t *hkey = s_hot_key + (size_t)wave * HOT_N * WK;
+                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
+                        int at = -1;
+                        for (int q = 0; q < HOT_N && at < 0; ++q) {
+                            if (!hcnt[q]) continue;
+                            bool same = true;
+                            for (int t = 0; t < WK; ++t) same &= (hkey[q * WK + t] == s_homh[b * WK + t]);
+                            if (same) at = q;
+                        }
+                        if (at < 0)
+                            for (int q = 0; q < HOT_N; ++q)
+                                if (!hcnt[q]) {
+                                    at = q;
+                                    for (int t = 0; t < WK; ++t) hkey[q * WK + t] = s_homh[b * WK + t];
+                                    break;
+                                }
+                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
+                        else if (!(dbg & 1)) {
+                            uint64_t rec[RW];
+                            for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? s_homh[b * WK + (t < WK ? t : 0)] : 0ULL;
+                            defer_append<RW>(pk, rec, tot);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid] && !(dbg & 1)) {
+        uint64_t rec[RW];
+        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? s_hot_key[(size_t)tid * WK + (t < WK ? t : 0)] : 0ULL;
+        defer_append<RW>(pk, rec, s_hot_cnt[tid]);
+    }
+    if (lane == 0) log_cnt[region] = min(fill, cap32);   // (k-mers are counted by strip_desc_wide_kernel)
+    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
+}
+
+
 // addKmer for encoded k-mers already on the device (API batches, merge inserts).
 template <int WK>
 __global__ __launch_bounds__(NT) void add_kmers_kernel(TableParams p, const uint64_t *kmers,

@@ -760,6 +760,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)walk_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+        HIP_TRY(hipFuncSetAttribute((const void *)walk_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         m->attr_done = true;
     }
     return TSX_HIP_OK;
@@ -969,7 +971,11 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const uint64_t maxrec = (p.line_mask == 3 ? own_end / 2 : own_end) + 65536;
     const uint32_t nown = 1u << (p.lg - p.l);
     // the scan kernels of this path keep one log region per WAVE
-    const int scan_wgs = (p.wk == 1) ? SCAN_WG_PER_CU : 2;
+    const char *scan2_env = getenv("TSX_HIP_SCAN2");   // 0: scan_log_kernel (one kernel) where the keys go to a log
+    const bool scan2 = !scan2_env || atoi(scan2_env) != 0;
+    // workgroups per CU of the kernel that writes the key log: scan_log_wide_kernel 2 (LDS, registers); the walk
+    // kernels of the two-kernel form carry no tile state: 6 for two-limb keys, 3 above (LUT of up to 32 KiB)
+    const int scan_wgs = (p.wk == 1) ? SCAN_WG_PER_CU : (scan2 ? (p.wk == 2 ? 6 : 3) : 2);
     const int gs = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * scan_wgs);
     const int greg = gs * (NT / 64);
     PartPlan pl;
@@ -984,8 +990,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     static const int desc_wgs = getenv("TSX_HIP_DESC_WGS") ? std::min(16, std::max(1, atoi(getenv("TSX_HIP_DESC_WGS")))) : 8;
     const int gd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * desc_wgs), gdreg = gd * (NT / 64);
     const bool want_fuse = fuse && !shard_send && p.wk == 1;
-    const char *scan2_env = getenv("TSX_HIP_SCAN2");   // 0: scan_log_kernel (one kernel) where the keys go to a log
-    const bool scan2 = !scan2_env || atoi(scan2_env) != 0;
+
     int rc = plan_partition(m, maxrec, (want_fuse && fuse == 2) ? std::max(greg, gdreg) : greg, true, shard_send ? nown : 0, st,
                             pl, want_fuse ? g_sp : 0);
     if (rc == TSX_HIP_OK && want_fuse && !pl.fused)   // a one-level table: the key log form, planned for its own regions
@@ -1048,6 +1053,32 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
                            hist_nb, hist_shift);
+    } else if (scan2) {
+        // multi-limb keys, two kernels as well: descriptions (first k-mer + entering bases + validity) into buffer 1,
+        // then the walk with every lane busy
+        const int du = (2 * p.wk + 2 + 3) / 4;
+        const uint64_t desc_cap = ((ntiles + gd - 1) / gd) * 64;
+        rc = grow(st, m->d_buf[1], m->buf_bytes[1], (size_t)gdreg * desc_cap * du * 16);
+        if (rc != TSX_HIP_OK) return rc;
+        pl.buf1 = m->d_buf[1];
+        {
+            size_t have = m->desc_cnt_entries;
+            rc = grow(st, m->d_desc_cnt, have, (size_t)gdreg * 8);
+            m->desc_cnt_entries = have;
+            if (rc != TSX_HIP_OK) return rc;
+        }
+#define TSX_WIDE2(WKV)                                                                                                      \
+        hipLaunchKernelGGL((strip_desc_wide_kernel<WKV>), dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,      \
+                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], desc_cap, m->d_desc_cnt);              \
+        hipLaunchKernelGGL((walk_log_wide_kernel<WKV>), dim3(gs), dim3(NT), lut_bytes, st, pp, (const uint4 *)m->d_buf[1],   \
+                           desc_cap, (const unsigned long long *)m->d_desc_cnt, (uint32_t)gdreg, m->dbg, m->d_buf[0],        \
+                           pl.log_cap, pl.c_log, pl.d_hist, hist_nb, hist_shift)
+        switch (p.wk) {
+            case 2: TSX_WIDE2(2); break;
+            case 3: TSX_WIDE2(3); break;
+            default: TSX_WIDE2(4); break;
+        }
+#undef TSX_WIDE2
     } else {
         switch (p.wk) {
             case 2: hipLaunchKernelGGL((scan_log_wide_kernel<2>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
