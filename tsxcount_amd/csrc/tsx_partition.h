@@ -184,7 +184,11 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         }
     };
     uint32_t round = 0;   // flush rounds so far (workgroup-uniform)
-    auto flush = [&](bool all) {
+    // `between` runs after phase (A) and its barrier, before the first store of phase (B): the main loop waits for
+    // the next batch's loads THERE.  vmcnt counts loads and stores in one in-order queue: waiting for those loads
+    // behind the flush (as the first version did) also waited for the flush's own stores -- every batch paid a full
+    // store latency, half of the kernel's time.
+    auto flush = [&](bool all, auto &&between) {
         const uint32_t par = round & 1u;
         ++round;
         if (tid == 0) s_njobs[par ^ 1u] = 0;   // next round's counter: nobody reads or writes it in this round
@@ -204,6 +208,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
             if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;   // about half of the lists in a usual round
         }
         lds_barrier();
+        between();
         const uint32_t oct = tid >> 3, ol = tid & 7;  // (B): an octet of lanes per job
         if (dbg & 512) return;  // ablation: bookkeeping only
         const uint32_t njobs = s_njobs[par];
@@ -337,15 +342,17 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
             }
         }
         lds_barrier();
-        flush(false);
+        flush(false, [&]() {
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), spelled out: the compiler would sink the copies (and the wait) behind the stores
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+#pragma unroll
+                for (int t = 0; t < RW; ++t) cur[q][t] = nxt[q][t];
+        });
         lds_barrier();
-#pragma unroll
-        for (int q = 0; q < RPT; ++q)
-#pragma unroll
-            for (int t = 0; t < RW; ++t) cur[q][t] = nxt[q][t];
         bc = bn;
     }
-    flush(true);
+    flush(true, []() {});
     lds_barrier();
     if (dst_cnt)
         for (uint32_t b = tid; b < nb; b += RING_NT) {
@@ -808,7 +815,10 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     // partition_ring_kernel's flush for one-word records and fixed-capacity lists: (A) one thread per list decides
     // how many words leave (whole 128-B lines of the destination, or everything at the end), (B) an octet of lanes
     // per list copies them.
-    auto flush = [&](bool all) {
+    // wait_loads: the flush of a batch's first quarter waits for the NEXT batch's descriptions between its phases,
+    // i.e. before the batch's first store: vmcnt is one in-order queue of loads and stores, and a wait at the top
+    // of the next batch would also wait for this batch's last stores.
+    auto flush = [&](bool all, bool wait_loads) {
         const uint32_t par = round & 1u;
         ++round;
         if (tid == 0) s_njobs[par ^ 1u] = 0;
@@ -826,6 +836,7 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
             if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;
         }
         lds_barrier();
+        if (wait_loads) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         const uint32_t oct = tid >> 3, ol = tid & 7;
         const uint32_t njobs = s_njobs[par];
         // about 45 % of the lists have a line to send after a half strip: two jobs per octet and pass
@@ -980,13 +991,13 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                     }
                 }
                 lds_barrier();
-                flush(false);
+                flush(false, j0 == 0);
                 lds_barrier();
             }
         }
     }
     lds_barrier();
-    flush(true);
+    flush(true, false);
     lds_barrier();
     for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * G + wg] = min(s_cur[b], cap32);
     if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) side_insert(s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
