@@ -24,7 +24,10 @@ bits = world.bit_length() - 1
 # their own exchange while the next window is scanned
 # l = 23: a table split by two radix levels -- level 1 of the received keys then runs window by window
 # (tsx_hip_shard_l1_window_device), level 2 + build once at the end
-for k, l, n_reads, windows in ((31, 17, 240, 3), (21, 15, 30, 1), (32, 19, 700, 5), (31, 23, 1500, 3)):
+# (there: description exchange at world sizes <= 4 -- TSX_HIP_SHARD_MODE=keys runs the key exchange on the same table)
+for k, l, n_reads, windows, mode in ((31, 17, 240, 3, "auto"), (21, 15, 30, 1, "auto"), (32, 19, 700, 5, "auto"),
+                                     (31, 23, 1500, 3, "auto"), (31, 23, 1500, 3, "keys")):
+    os.environ["TSX_HIP_SHARD_MODE"] = mode
     first, cnt = TD.shard_reads(n_reads, rank, world)
     text = synth.fastq(66, first, cnt)
     buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")

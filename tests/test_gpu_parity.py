@@ -925,8 +925,11 @@ def test_config5_k127_load_0p8_overflow_merge(world):
         assert "MERGE OK" in o
 
 
-def test_sharded_counting_world_8_in_one_process(T):
-    """shard_bits = 3, the value the 8-GPU node uses: eight shards of one table, eight ShardedCounter
+@pytest.mark.parametrize("l,mode", [(16, "auto"), (23, "keys"), (23, "desc")])
+def test_sharded_counting_world_8_in_one_process(T, monkeypatch, l, mode):
+    """(l = 23: a table split by two radix levels -- "keys": level 1 window by window as the keys arrive, "desc": strip
+    descriptions all-gathered, every shard walks all of them and keeps what it owns.)
+    shard_bits = 3, the value the 8-GPU node uses: eight shards of one table, eight ShardedCounter
     pipelines (3 windows each), run as eight THREADS of this process on cuda:0 with the collectives replaced
     by device copies behind a barrier (tests/_thread_comm.py) -- a one-GPU box admits at most 6 processes on
     the card.  Same checks as the multi-process test: sum over shards == oracle, every k-mer on one shard."""
@@ -936,7 +939,8 @@ def test_sharded_counting_world_8_in_one_process(T):
     from oracle.oracle import Oracle
     from tsxcount_amd import distributed as TD
     from tsxcount_amd import synth
-    world, k, l, n_reads = 8, 31, 16, 400
+    monkeypatch.setenv("TSX_HIP_SHARD_MODE", mode)
+    world, k, n_reads = 8, 31, 400
     tw = ThreadWorld(world)
     whole = Oracle(k, 21, 4, seed=1)
     whole.count_fastq(synth.fastq(66, 0, n_reads))
@@ -955,6 +959,7 @@ def test_sharded_counting_world_8_in_one_process(T):
             torch.cuda.synchronize()
             sc.step(buf.data_ptr(), len(text))
             assert sc.last["key_sum_diff"] == 0
+            assert sc.last.get("mode", "keys") == ("desc" if mode == "desc" else "keys")
             st = m.stats()
             assert st["insert_failures"] == 0
             got[rank] = (m.getKmerCounts(kmers), st)

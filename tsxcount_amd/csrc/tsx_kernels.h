@@ -630,7 +630,8 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
 // descriptions, one per lane, every lane busy, and does first window + rolls + level-1 rings.  k <= 32.
 __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
                                                            int head_open, const uint32_t *tile_line, uint64_t ntiles,
-                                                           uint4 *desc, uint64_t desc_cap, unsigned long long *desc_cnt) {
+                                                           uint4 *desc, uint64_t desc_cap, unsigned long long *desc_cnt,
+                                                           unsigned long long *kmer_sum) {
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
     __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
     __shared__ uint64_t s_le[TILE / 64];
@@ -725,6 +726,7 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
     if (lane == 0) {
         if (added) atomicAdd(&p.stats[ST_KMERS], added);
+        if (added && kmer_sum) atomicAdd(kmer_sum, added);   // sharded runs: checked against what the walks keep
         desc_cnt[region] = fill;
     }
 }

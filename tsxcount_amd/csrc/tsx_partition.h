@@ -738,6 +738,37 @@ __global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, cons
     }
 }
 
+// Descriptions of one text window, packed for the exchange of a sharded run: strip_desc_kernel leaves one region per
+// wave; desc_prefix_kernel (one workgroup) turns the region sizes into offsets, desc_pack_kernel copies the regions
+// back to back.  total[0] = descriptions in all.
+__global__ __launch_bounds__(1024) void desc_prefix_kernel(const unsigned long long *cnt, uint32_t nregions,
+                                                           unsigned long long *offs, unsigned long long *total) {
+    __shared__ unsigned long long s_w[16];
+    const uint32_t tid = threadIdx.x, per = (nregions + 1023u) / 1024u;
+    unsigned long long sum = 0;
+    for (uint32_t i = 0; i < per; ++i) { const uint32_t r = tid * per + i; if (r < nregions) sum += cnt[r]; }
+    const unsigned long long inc = wave_incl_scan64(sum);
+    if ((tid & 63) == 63) s_w[tid >> 6] = inc;
+    __syncthreads();
+    unsigned long long base = inc - sum;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) base += s_w[w];
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t r = tid * per + i;
+        if (r < nregions) { offs[r] = base; base += cnt[r]; }
+    }
+    if (tid == 1023) total[0] = base;
+}
+__global__ __launch_bounds__(256) void desc_pack_kernel(const uint4 *desc, uint64_t desc_cap, const unsigned long long *cnt,
+                                                        const unsigned long long *offs, uint32_t nregions, uint4 *out,
+                                                        uint64_t out_cap) {
+    for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+        const uint64_t n = min((uint64_t)cnt[r], desc_cap), o = offs[r];
+        const uint4 *src = desc + (uint64_t)r * desc_cap;
+        for (uint64_t i = threadIdx.x; i < n; i += 256)
+            if (o + i < out_cap) out[o + i] = src[i];
+    }
+}
+
 // ---- walk_part_kernel: the second half of the two-kernel scan (strip_desc_kernel, tsx_kernels.h) -----------
 // Reads strip descriptions (48 bases as 2-bit codes + 16 validity bits), ONE PER LANE, every lane busy: first
 // window by the 4-bit-group LUT, 15 rolls, the keys into the level-1 rings, bursts to the workgroup's sub-lists --
@@ -748,7 +779,9 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                                                             const unsigned long long *desc_cnt, uint32_t nregions, int dbg,
                                                             uint64_t *dst, uint64_t dst_cap, unsigned long long *dst_cnt,
                                                             uint32_t nb, uint32_t shift, uint64_t *ovq_all,
-                                                            uint32_t *ovq_cnt, uint32_t ovq_cap) {
+                                                            uint32_t *ovq_cnt, uint32_t ovq_cap, uint64_t n_packed,
+                                                            uint32_t dst_g0, uint32_t dst_gtot, int own_only,
+                                                            unsigned long long *emit_sum) {
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
@@ -768,9 +801,18 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     uint32_t *s_job = s_cur + nb;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t G = gridDim.x, wg = blockIdx.x;
+    const uint32_t wg = blockIdx.x;
     const uint32_t cap32 = (uint32_t)min(dst_cap, (uint64_t)0xFFFFFFF0u);
-    auto word_of = [&](uint32_t b, uint32_t at) -> uint64_t * { return dst + ((uint64_t)(b * G + wg) * (uint64_t)cap32 + at); };
+    // Sharded runs (descriptions gathered from every GPU, tsx_hip_shard_walk_device): the descriptions are ONE packed
+    // array of n_packed entries cut into runs of desc_cap; only the keys this GPU owns are kept (own_only); the launch
+    // fills lists (b, dst_g0 + g) of dst_gtot per bucket.  Local runs: n_packed = 0, dst_g0 = 0, dst_gtot = G.
+    const uint32_t gl = dst_g0 + wg;
+    auto word_of = [&](uint32_t b, uint32_t at) -> uint64_t * { return dst + ((uint64_t)(b * dst_gtot + gl) * (uint64_t)cap32 + at); };
+    auto is_mine = [&](uint64_t hk) -> bool {
+        if (!own_only) return true;
+        const uint64_t h1[1] = {hk};
+        return owner_shard<1>(p, h1) == p.shard;
+    };
     if (tid < 64) s_roll[tid] = p.roll[tid];
     if (tid < 256) s_lut4[tid] = p.roll[64 + tid];
     if (tid < 4) {
@@ -786,6 +828,7 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_th[b] = 0; }
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
     unsigned long long added = 0;   // (k-mers are counted by strip_desc_kernel)
+    unsigned long long emitted = 0; // sharded runs: k-mer occurrences this GPU kept (sum over GPUs == k-mers scanned)
     uint32_t spilled = 0;
     const uint32_t k = (uint32_t)p.k;
     const uint32_t ngrp = (2u * k + 3u) / 4u;
@@ -881,7 +924,8 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
 
     lds_barrier();
     for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
-        const uint32_t nr = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
+        const uint32_t nr = n_packed ? (uint32_t)(((uint64_t)r * desc_cap < n_packed) ? min(desc_cap, n_packed - (uint64_t)r * desc_cap) : 0ULL)
+                                     : (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
         const uint4 *rd = desc + (uint64_t)r * desc_cap;
         uint4 dn = (tid < nr) ? rd[tid] : make_uint4(0, 0, 0, 0);
         for (uint32_t base = 0; base < nr; base += SP_NT) {
@@ -937,7 +981,8 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                     uint32_t tot = (uint32_t)__popc(hv & y);
                     if (__ballot(tot != 0u) == 0ULL) continue;
                     for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                    if (lane == 0) {
+                    if (lane == 0 && is_mine(s_homh[b])) {
+                        emitted += tot;
                         const uint64_t key = s_homh[b];
                         uint64_t *hkey = s_hot_key + wave * HOT_N;
                         uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
@@ -967,17 +1012,24 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                             h = (h >> 2) ^ s_roll[idx];
                         }
                     }
-                    if (__ballot(s4 != 0u) != 0ULL) {
+                    uint32_t m4 = s4;   // positions of this quarter whose keys this GPU keeps
+                    if (own_only) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (((s4 >> j) & 1u) && !is_mine(hs[j])) m4 &= ~(1u << j);
+                        emitted += (unsigned long long)__popc(m4);
+                    }
+                    if (__ballot(m4 != 0u) != 0ULL) {
                         uint32_t bq[4];
                         unsigned long long sl[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             bq[j] = (uint32_t)(hs[j] >> shift) & (nb - 1);
-                            sl[j] = ((s4 >> j) & 1u) ? atomicAdd(&s_th[bq[j]], 1ULL) : 0ULL;
+                            sl[j] = ((m4 >> j) & 1u) ? atomicAdd(&s_th[bq[j]], 1ULL) : 0ULL;
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            if ((s4 >> j) & 1u) {
+                            if ((m4 >> j) & 1u) {
                                 const uint32_t b = bq[j];
                                 if ((uint32_t)sl[j] - (uint32_t)(sl[j] >> 32) < CAP) {
                                     s_stage[(b << SP_CAPBITS) + (((uint32_t)sl[j] ^ b) & cmask)] = hs[j];
@@ -999,10 +1051,14 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     lds_barrier();
     flush(true, false);
     lds_barrier();
-    for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * G + wg] = min(s_cur[b], cap32);
+    for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * dst_gtot + gl] = min(s_cur[b], cap32);
     if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) side_insert(s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
     if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
     if (tid < (SP_NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    if (emit_sum) {
+        for (int d = 32; d > 0; d >>= 1) emitted += __shfl_down(emitted, d, 64);
+        if (lane == 0 && emitted) atomicAdd(emit_sum, emitted);
+    }
     for (int d = 32; d > 0; d >>= 1) { added += __shfl_down(added, d, 64); spilled += __shfl_down(spilled, d, 64); }
     if (lane == 0) {
         if (added) atomicAdd(&p.stats[ST_KMERS], added);

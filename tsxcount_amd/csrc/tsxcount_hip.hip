@@ -917,8 +917,12 @@ struct ShardOut {
 // before it); head_open = the piece starts in the middle of a line.
 // shard_send != nullptr: sharded scan -- the keys are not built into the local table but
 // split by owner into shard_send (counts per owner to shard_counts), hot keys to `hot`.
+// Sharded run, description exchange: the piece is only DESCRIBED (strip_desc_kernel), the descriptions packed
+// into out[0 .. *count).
+struct DescOut { uint4 *out = nullptr; uint64_t cap = 0; unsigned long long *count = nullptr, *sum = nullptr; };
+
 static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
-                           hipStream_t st, ShardOut sh = ShardOut(), HotOut hot = HotOut()) {
+                           hipStream_t st, ShardOut sh = ShardOut(), HotOut hot = HotOut(), DescOut dsc = DescOut()) {
     uint64_t *shard_send = sh.send;
     const uint64_t shard_cap = sh.send_cap;
     unsigned long long *shard_counts = sh.counts;
@@ -950,6 +954,29 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
                            (const uint32_t *)chunk);
     }
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
+    if (dsc.out) {
+        const int gdd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8), gdr = gdd * (NT / 64);
+        const uint64_t dcap = ((ntiles + gdd - 1) / gdd) * 64;
+        int rcd = grow(st, m->d_buf[1], m->buf_bytes[1], (size_t)gdr * dcap * 16);
+        if (rcd != TSX_HIP_OK) return rcd;
+        {   // region sizes | region offsets | total
+            size_t have = m->desc_cnt_entries;
+            rcd = grow(st, m->d_desc_cnt, have, ((size_t)2 * gdr + 8) * 8);
+            m->desc_cnt_entries = have;
+            if (rcd != TSX_HIP_OK) return rcd;
+        }
+        unsigned long long *d_cnt = m->d_desc_cnt, *d_offs = d_cnt + gdr, *d_tot = d_offs + gdr;
+        hipLaunchKernelGGL(strip_desc_kernel, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
+                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum);
+        hipLaunchKernelGGL(desc_prefix_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long *)d_cnt, (uint32_t)gdr,
+                           d_offs, d_tot);
+        hipLaunchKernelGGL(desc_pack_kernel, dim3(std::min(gdr, m->cus * 8)), dim3(256), 0, st, (const uint4 *)m->d_buf[1], dcap,
+                           (const unsigned long long *)d_cnt, (const unsigned long long *)d_offs, (uint32_t)gdr, dsc.out, dsc.cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(dsc.count, d_tot, 8, hipMemcpyDeviceToDevice, st));
+        if (ev) for (int i = 2; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+        return TSX_HIP_OK;
+    }
     const size_t lut_bytes = m->lut.size() * 8;
     const int g3 = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 3);
 
@@ -1020,11 +1047,12 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             rc = grow(st, m->d_buf[0], m->buf_bytes[0], (size_t)gdreg * desc_cap * 16);
             if (rc != TSX_HIP_OK) return rc;
             hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
-                               (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log);
+                               (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log, (unsigned long long *)nullptr);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(walk_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
                                (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
-                               (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
+                               (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
+                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr);
         } else {
             hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
@@ -1044,7 +1072,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             if (rc != TSX_HIP_OK) return rc;
         }
         hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
-                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], desc_cap, m->d_desc_cnt);
+                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], desc_cap, m->d_desc_cnt,
+                           (unsigned long long *)nullptr);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(walk_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, (const uint4 *)m->d_buf[1], desc_cap,
                            (const unsigned long long *)m->d_desc_cnt, (uint32_t)gdreg, m->dbg, m->d_buf[0], pl.log_cap,
@@ -1316,6 +1345,90 @@ extern "C" int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_ke
                        m->d_ovq + ((size_t)nq2 + (size_t)window * rw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)window * rw, OVQ_CAP,
                        (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, (unsigned long long *)dev_key_sum,
                        window * rw, g1);
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+// ---- sharded run, DESCRIPTION exchange (small world sizes) -------------------------------------------------------
+// Keys cost 8 bytes per k-mer occurrence on the wire; a strip description (16 bytes) stands for up to 16 of them.
+// Instead of sending every key to its owner, every GPU describes its window (tsx_hip_shard_desc_window_device), the
+// descriptions are ALL-GATHERED, and every GPU walks all of them, keeping the keys it owns
+// (tsx_hip_shard_walk_device): N x the rolling work, N/8 of the traffic of the key exchange -- a quarter at N = 2.
+extern "C" int tsx_hip_shard_desc_capacity(tsx_hip_map *m, size_t text_bytes, size_t *descs_out) {
+    if (!m || !descs_out) return TSX_HIP_EINVAL;
+    *descs_out = text_bytes / 16 + 4096;   // one description per 16 start positions at most
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off,
+                                                size_t win_len, void *dev_desc, size_t desc_cap, void *dev_count,
+                                                void *dev_kmer_sum, void *stream) {
+    if (!m || (!dev_text && n_total) || ((uintptr_t)dev_text & 15) || (win_off & 15) || !dev_desc || ((uintptr_t)dev_desc & 15) ||
+        !dev_count || win_off > n_total || win_len > n_total - win_off)
+        return TSX_HIP_EINVAL;
+    if (!tsx_hip_shard_l1_supported(m)) return TSX_HIP_EINVAL;
+    if (win_len >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;
+    if (desc_cap < win_len / 16 + 1) return TSX_HIP_ERANGE;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    if (win_off == 0) HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(dev_count, 0, 8, st));
+    if (win_len == 0) return TSX_HIP_OK;
+    DescOut dsc;
+    dsc.out = (uint4 *)dev_desc; dsc.cap = desc_cap; dsc.count = (unsigned long long *)dev_count;
+    dsc.sum = (unsigned long long *)dev_kmer_sum;
+    const size_t halo = (size_t)m->p.k - 1;
+    const size_t len = std::min(win_len + halo, n_total - win_off);
+    return run_fastq_piece(m, (const uint8_t *)dev_text + win_off, len, win_len, win_off ? -1 : 0, st, ShardOut(), HotOut(), dsc);
+}
+
+// Walks n_desc packed descriptions (any GPU's), keeps the keys this shard owns and partitions them by radix level 1
+// into list set `slot` of `nslots` (slot 0 plans for est_total_keys owned keys in all).  dev_emit_sum += k-mer
+// occurrences kept.  Then tsx_hip_shard_build_l1_device.
+extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, uint32_t slot, uint32_t nslots,
+                                         size_t est_total_keys, void *dev_emit_sum, void *stream) {
+    if (!m || (!dev_desc && n_desc) || ((uintptr_t)dev_desc & 15) || nslots == 0 || slot >= nslots) return TSX_HIP_EINVAL;
+    if (!tsx_hip_shard_l1_supported(m)) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    if (!m->sh_pl) m->sh_pl = new PartPlan();
+    PartPlan &pl = *m->sh_pl;
+    if (slot == 0) {
+        // lists per slot: two workgroups per CU while the pieces of a bucket stay within what a level-2 workgroup walks
+        uint32_t gw = (uint32_t)m->cus * 2;
+        while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * 8) gw /= 2;
+        m->sh_rw = gw;
+        m->sh_windows = nslots;
+        const int g1 = (int)(gw * nslots);
+        const uint64_t maxrec = est_total_keys + 65536;
+        std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
+        std::swap(m->d_cnt, m->sh_cnt); std::swap(m->cnt_entries, m->sh_cnt_entries);
+        int rc = plan_partition(m, maxrec, g1, false, 0, st, pl, g1);
+        std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
+        std::swap(m->d_cnt, m->sh_cnt); std::swap(m->cnt_entries, m->sh_cnt_entries);
+        if (rc != TSX_HIP_OK) return rc;
+        if (!pl.fused) return TSX_HIP_EINVAL;
+        rc = ensure_deferred(m, maxrec, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_def_n, 0, 8, st));
+        const uint32_t nq2 = pl.nb1 * pl.cpr2;
+        rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_ovq_cnt, 0, ((size_t)nq2 + pl.G1) * 4, st));
+    } else if (m->sh_windows != nslots || !pl.fused) {
+        return TSX_HIP_EINVAL;
+    }
+    if (n_desc == 0) return TSX_HIP_OK;
+    const uint32_t gw = m->sh_rw, nq2 = pl.nb1 * pl.cpr2;
+    const uint64_t chunk = (n_desc + gw - 1) / gw;   // descriptions per workgroup
+    TableParams pp = m->p;
+    pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
+    const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);
+    hipLaunchKernelGGL(walk_part_kernel, dim3(gw), dim3(SP_NT), lds, st, pp, (const uint4 *)dev_desc, chunk,
+                       (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                       (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
+                       m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
+                       (unsigned long long *)dev_emit_sum);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }

@@ -271,9 +271,119 @@ class ShardedCounter:
         self.ev_scan[b].record(self.cs)
         return rc
 
+    def _mode(self):
+        """"keys": every key travels to its owner (8 B per k-mer occurrence, (N-1)/N of them);  "desc": strip
+        descriptions (16 B per up-to-16 occurrences) are all-gathered and every GPU walks all of them, keeping what it
+        owns: N x the rolling work for N/8 of the bytes -- the better deal up to N = 4 (TSX_HIP_SHARD_MODE overrides)."""
+        want = os.environ.get("TSX_HIP_SHARD_MODE", "auto")
+        ok = bool(self.m._lib.tsx_hip_shard_l1_supported(self.m.handle))
+        if want == "keys" or not ok:
+            return "keys"
+        if want == "desc":
+            return "desc"
+        return "desc" if self.world <= 4 else "keys"
+
+    def _step_desc(self, text_ptr, nbytes):
+        """step() by description exchange.
+
+            compute stream   desc(0) desc(1) walk(0,*) desc(2) walk(1,*) ...   level 2 + build
+            exchange stream        gather(0)       gather(1)      ...
+        """
+        from . import OK, TSXException, _check
+        m, L, vp = self.m, self.m._lib, ctypes.c_void_p
+        world, comm = self.world, self.comm
+        nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
+        nslots = nwin * world
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        if not hasattr(self, "dsc"):
+            cap = ctypes.c_size_t(0)
+            _check(L.tsx_hip_shard_desc_capacity(m.handle, self.win_bytes + 256, ctypes.byref(cap)))
+            self.dsc_cap = cap.value
+            self.dsc = [torch.empty((2 * self.dsc_cap,), **i64) for _ in range(2)]       # 16 B per description
+            self.dsc_n = [torch.zeros((1,), **i64) for _ in range(2)]
+            self.dsc_all = [torch.zeros((0,), **i64) for _ in range(self.windows)]
+            self.emit = torch.zeros((2,), **i64)     # [0] += k-mer occurrences described, [1] += occurrences kept by the walks
+        self.cs.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.cs):
+            self.emit.zero_()
+        late = None      # a failure only this rank has seen: it stays in the collectives, all raise after the last all-reduce
+
+        def desc(i):
+            b = i & 1
+            off = i * self.win_bytes
+            ln = max(0, min(self.win_bytes, nbytes - off))
+            rc = L.tsx_hip_shard_desc_window_device(m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln,
+                                                    vp(self.dsc[b].data_ptr()), self.dsc_cap, vp(self.dsc_n[b].data_ptr()),
+                                                    vp(self.emit.data_ptr()), vp(self.cs.cuda_stream))
+            self.ev_scan[b].record(self.cs)
+            return rc
+
+        rc_next = desc(0)
+        est_total, total_desc = 0, 0
+        for i in range(nwin):
+            b = i & 1
+            rc_this = rc_next
+            if i + 1 < nwin:
+                if i >= 1:
+                    self.cs.wait_event(self.ev_exch[(i + 1) & 1])   # gather i-1 has read the buffer desc(i+1) writes
+                rc_next = desc(i + 1)                               # queued before the host waits for window i
+            with torch.cuda.stream(self.xs):
+                self.xs.wait_event(self.ev_scan[b])
+                mine = torch.stack([self.dsc_n[b][0], torch.tensor(int(rc_this), **i64)])
+                allm = torch.empty((2 * world,), **i64)
+                comm.all_gather(allm, mine)
+                host = allm.cpu().view(world, 2)                    # the one host wait of the window
+                counts = [int(x) for x in host[:, 0].tolist()]
+                status = [int(x) for x in host[:, 1].tolist()]
+                if any(s != OK for s in status):                    # every rank sees the same statuses: all leave together
+                    late = late or (i, status)
+                    break
+                nmax = max(max(counts), 1)
+                if self.dsc_all[i].numel() < 2 * nmax * world:
+                    self.dsc_all[i] = torch.empty((2 * nmax * world,), **i64)
+                comm.all_gather(self.dsc_all[i][:2 * nmax * world], self.dsc[b][:2 * nmax])
+                self.ev_exch[b].record(self.xs)
+            total_desc += sum(counts)
+            self.cs.wait_event(self.ev_exch[b])
+            if i == 0:
+                est_total = int(sum(counts) * 16 * nwin / world * 1.1) + 65536
+            for src in range(world):
+                if late is not None:
+                    break
+                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.dsc_all[i].data_ptr() + src * nmax * 16), counts[src],
+                                                 i * world + src, nslots, est_total, vp(self.emit[1:].data_ptr()),
+                                                 vp(self.cs.cuda_stream))
+                if rc != OK:
+                    late = (i, [rc])
+        self.cs.wait_stream(self.xs)
+        failure = late
+        if failure is None and total_desc:
+            rc = L.tsx_hip_shard_build_l1_device(m.handle, vp(self.cs.cuda_stream))
+            if rc != OK:
+                failure = (nwin, [rc])
+        self.cs.synchronize()
+        self.xs.synchronize()
+        em = [int(x) for x in self.emit.tolist()]
+        fin = torch.tensor([em[0] - em[1], 0 if failure is None else 1], dtype=torch.int64,
+                           device="cpu" if comm.gloo else self.dev)
+        comm.all_reduce(fin, "sum") if world > 1 else None
+        diff, nfail = int(fin[0].item()), int(fin[1].item())
+        self.last = {"windows": nwin, "received_keys": em[1], "key_sum_diff": diff, "mode": "desc"}
+        if nfail:
+            if failure is not None:
+                bad = [s for s in failure[1] if s != OK]
+                _check(bad[0])
+            raise TSXException(-4, "sharded step: another rank failed")
+        if diff != 0:
+            raise RuntimeError("sharded step: k-mer occurrences scanned - kept, over all ranks = %d" % diff)
+        m.sync()
+        return em[1]
+
     def step(self, text_ptr, nbytes):
         """Count one FASTQ text (device pointer, 16-byte aligned) of this rank's reads into the sharded table."""
         from . import OK, TSXException, _check
+        if self._mode() == "desc":
+            return self._step_desc(text_ptr, nbytes)
         m, L, vp = self.m, self.m._lib, ctypes.c_void_p
         world, rank, comm = self.world, self.rank, self.comm
         nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
