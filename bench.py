@@ -307,6 +307,13 @@ def main():
                  "level1": "partition_ring_kernel (level 1)", "level2": "partition_ring_kernel (level 2)",
                  "build": "build_segments_stream_kernel" if (m.wk == 1 and m.layout.entry_limbs == 1)
                  else "build_segments_wide_stream_kernel<%d>" % m.wk}
+        if sharded and sc._mode() == "desc":
+            # description exchange: "scan" = strip_desc_kernel + pack of every window, "level1" = the walks over the
+            # descriptions of all GPUs (with the later windows' descriptions interleaved), then level 2 and the build
+            names["scan"] = "strip_desc_kernel + desc_pack_kernel"
+            names["level1"] = "walk_part_kernel (descriptions of all %d GPUs)" % world
+            stage_bytes["scan"] = nbytes + nbytes // 2 * 2          # text read; descriptions written and packed
+            stage_bytes["level1"] = world * (nbytes // 2) + rec_b * keys_logged
         stage_ms = {k2: stage[k2] / pieces for k2 in names}
         dom = max(stage_ms, key=lambda k2: stage_ms[k2])   # the kernel a step spends most time in
         kern_ms = stage_ms[dom]
@@ -333,7 +340,9 @@ def main():
                                    "k=%d, table 2^%d slots/GPU, %s insert path%s"
                                    % (args.reads, kmers_rank, args.k, args.l,
                                       "partitioned" if partitioned else "atomic",
-                                      (", table sharded by slot range, keys exchanged by one RCCL all-to-all" if sharded
+                                      ((", table sharded by slot range, strip descriptions all-gathered over RCCL, every GPU walks all and keeps what it owns"
+                                        if sc._mode() == "desc" else
+                                        ", table sharded by slot range, keys exchanged by one RCCL all-to-all per window") if sharded
                                        else ", per-GPU tables merged over RCCL all-to-all") if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
                        "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL",

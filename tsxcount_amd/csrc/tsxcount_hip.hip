@@ -94,6 +94,7 @@ struct tsx_hip_map {
     std::vector<unsigned long long> h_regions;   // host copy of the region table of a sharded build (starts, then sizes)
     PartPlan *sh_pl = nullptr;                   // sharded run, level 1 per exchange window: the plan made at window 0,
     uint32_t sh_rw = 0, sh_windows = 0;          // regions per window, windows of the step,
+    bool sh_ev3 = false;                         // stage timing: the walks of a description exchange have recorded event 3
     unsigned long long *d_desc_cnt = nullptr;    // strips described per wave of strip_desc_kernel (key log form)
     size_t desc_cnt_entries = 0;
     uint64_t *sh_buf1 = nullptr;                 // and its own sub-list buffer and counters (the scans of the later
@@ -974,7 +975,10 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
                            (const unsigned long long *)d_cnt, (const unsigned long long *)d_offs, (uint32_t)gdr, dsc.out, dsc.cap);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(dsc.count, d_tot, 8, hipMemcpyDeviceToDevice, st));
-        if (ev) for (int i = 2; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+        if (ev) {   // the walks, level 2 and the build follow in other calls, which record 3..7 of the first window's tuple again
+            for (int i = 2; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+            m->ev_open.push_back((long)(ev - m->ev.data()));
+        }
         return TSX_HIP_OK;
     }
     const size_t lut_bytes = m->lut.size() * 8;
@@ -1418,6 +1422,10 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     } else if (m->sh_windows != nslots || !pl.fused) {
         return TSX_HIP_EINVAL;
     }
+    if (slot == 0 && m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
+        HIP_TRY(hipEventRecord(m->ev[(size_t)m->ev_open.front() + 3], st));   // "level 1" = the walks, up to the start of level 2
+        m->sh_ev3 = true;
+    }
     if (n_desc == 0) return TSX_HIP_OK;
     const uint32_t gw = m->sh_rw, nq2 = pl.nb1 * pl.cpr2;
     const uint64_t chunk = (n_desc + gw - 1) / gw;   // descriptions per workgroup
@@ -1441,8 +1449,9 @@ extern "C" int tsx_hip_shard_build_l1_device(tsx_hip_map *m, void *stream) {
     hipEvent_t *ev = nullptr;
     if (m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
         ev = &m->ev[(size_t)m->ev_open.front()];
-        HIP_TRY(hipEventRecord(ev[3], st));
+        if (!m->sh_ev3) HIP_TRY(hipEventRecord(ev[3], st));
     }
+    m->sh_ev3 = false;
     if (!m->ev_open.empty()) m->ev_open.pop_front();
     int rc = run_partition_build(m, *m->sh_pl, nullptr, nullptr, 0, st, ev);
     if (rc == TSX_HIP_OK && ev) HIP_TRY(hipEventRecord(ev[7], st));
