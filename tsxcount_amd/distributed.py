@@ -235,6 +235,8 @@ class ShardedCounter:
         if windows is None:
             windows = int(os.environ.get("TSX_HIP_SHARD_WINDOWS", "0")) or max(1, min(4, max_text_bytes // self.MIN_WINDOW))
         self.windows = max(1, int(windows))
+        if self._mode() == "desc":
+            self.windows = max(1, min(self.windows, 8 // self.world))
         self.win_bytes = max(4096, ((max_text_bytes + self.windows - 1) // self.windows + 4095) & ~4095)
         cap = ctypes.c_size_t(0)
         _check(hmap._lib.tsx_hip_shard_send_capacity(hmap.handle, self.win_bytes + 256, ctypes.byref(cap)))
@@ -293,7 +295,8 @@ class ShardedCounter:
         m, L, vp = self.m, self.m._lib, ctypes.c_void_p
         world, comm = self.world, self.comm
         nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
-        nslots = nwin * world
+        nslots = nwin * world   # (windows x sources) list sets; ShardedCounter.__init__ keeps windows * world <= 8, so
+                                # that every walk launch can run two workgroups per CU (level 2 walks <= 4096 pieces per bucket)
         i64 = dict(dtype=torch.int64, device=self.dev)
         if not hasattr(self, "dsc"):
             cap = ctypes.c_size_t(0)
