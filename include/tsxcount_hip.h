@@ -296,13 +296,15 @@ int tsx_hip_shard_build_l1_device(tsx_hip_map *m, void *stream);
  * descriptions are all-gathered, and every GPU walks all of them and keeps the keys it owns
  * (tsx_hip_shard_walk_device, one call per (window, source GPU) = slot of nslots; slot 0 plans for est_total_keys owned
  * keys; dev_emit_sum += k-mer occurrences kept -- over all GPUs that must equal the k-mers scanned).  N x the rolling
- * work for N/8 of the bytes on the wire.  Then tsx_hip_shard_build_l1_device.  Same support as
- * tsx_hip_shard_l1_supported. */
-int tsx_hip_shard_desc_capacity(tsx_hip_map *m, size_t text_bytes, size_t *descs_out);
+ * work for N/8 of the bytes on the wire.  long_desc: four neighbouring strips in one description of 32 bytes (96 bases +
+ * 64 validity bits) -- half the bytes again; dev_desc / desc_cap / n_desc then count those.  Then
+ * tsx_hip_shard_build_l1_device.  Same support as tsx_hip_shard_l1_supported. */
+int tsx_hip_shard_desc_capacity(tsx_hip_map *m, size_t text_bytes, int long_desc, size_t *descs_out);
 int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off, size_t win_len,
-                                     void *dev_desc, size_t desc_cap, void *dev_count, void *dev_kmer_sum, void *stream);
-int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, uint32_t slot, uint32_t nslots,
-                              size_t est_total_keys, void *dev_emit_sum, void *stream);
+                                     int long_desc, void *dev_desc, size_t desc_cap, void *dev_count, void *dev_kmer_sum,
+                                     void *stream);
+int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, int long_desc, uint32_t slot,
+                              uint32_t nslots, size_t est_total_keys, void *dev_emit_sum, void *stream);
 
 int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
                               void *stream);

@@ -925,7 +925,7 @@ def test_config5_k127_load_0p8_overflow_merge(world):
         assert "MERGE OK" in o
 
 
-@pytest.mark.parametrize("l,mode", [(16, "auto"), (23, "keys"), (23, "desc")])
+@pytest.mark.parametrize("l,mode", [(16, "auto"), (23, "keys"), (23, "desc"), (23, "desc16")])
 def test_sharded_counting_world_8_in_one_process(T, monkeypatch, l, mode):
     """(l = 23: a table split by two radix levels -- "keys": level 1 window by window as the keys arrive, "desc": strip
     descriptions all-gathered, every shard walks all of them and keeps what it owns.)
@@ -939,6 +939,9 @@ def test_sharded_counting_world_8_in_one_process(T, monkeypatch, l, mode):
     from oracle.oracle import Oracle
     from tsxcount_amd import distributed as TD
     from tsxcount_amd import synth
+    if mode == "desc16":   # one strip per description (16 bytes) instead of four (32 bytes)
+        monkeypatch.setenv("TSX_HIP_SHARD_LONG", "0")
+        mode = "desc"
     monkeypatch.setenv("TSX_HIP_SHARD_MODE", mode)
     world, k, n_reads = 8, 31, 400
     tw = ThreadWorld(world)

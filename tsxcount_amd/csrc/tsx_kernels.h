@@ -631,7 +631,9 @@ __global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const ui
 __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
                                                            int head_open, const uint32_t *tile_line, uint64_t ntiles,
                                                            uint4 *desc, uint64_t desc_cap, unsigned long long *desc_cnt,
-                                                           unsigned long long *kmer_sum) {
+                                                           unsigned long long *kmer_sum, int long_desc) {
+    // long_desc (the exchange of a sharded run): FOUR neighbouring strips in one description of 32 bytes -- 96 bases
+    // + 64 validity bits, half the bytes per start position (the 32 bases behind a strip's own 16 are shared).
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
     __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
     __shared__ uint64_t s_le[TILE / 64];
@@ -643,8 +645,8 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
     unsigned long long added = 0;
     const uint32_t k = (uint32_t)p.k;
     const uint32_t region = blockIdx.x * (NT / 64) + wave;
-    uint4 *my = desc + (uint64_t)region * desc_cap;
-    uint32_t fill = 0;  // wave-uniform
+    uint4 *my = desc + (uint64_t)region * desc_cap * (long_desc ? 2u : 1u);
+    uint32_t fill = 0;  // wave-uniform, in descriptions
     const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
     const uint64_t lt = (1ULL << lane) - 1ULL;
 
@@ -717,10 +719,25 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
         const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;
         const uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);
         added += (unsigned long long)__popc(vm);
-        const unsigned long long hb = __ballot(vm != 0u);
-        if (hb) {
-            if (vm) my[fill + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm);
-            fill += (uint32_t)__builtin_popcountll(hb);
+        if (!long_desc) {
+            const unsigned long long hb = __ballot(vm != 0u);
+            if (hb) {
+                if (vm) my[fill + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm);
+                fill += (uint32_t)__builtin_popcountll(hb);
+            }
+        } else {   // lanes 4q .. 4q+3 hold 64 consecutive start positions: lane 4q writes for all four
+            const uint32_t v1 = __shfl_down(vm, 1, 64), v2 = __shfl_down(vm, 2, 64), v3 = __shfl_down(vm, 3, 64);
+            const uint32_t vlo = vm | (v1 << 16), vhi = v2 | (v3 << 16);
+            const bool has = (lane & 3) == 0 && (vlo | vhi) != 0u;
+            const unsigned long long hb = __ballot(has);
+            if (hb) {
+                if (has) {
+                    uint4 *o = my + (uint64_t)(fill + (uint32_t)__builtin_popcountll(hb & lt)) * 2u;
+                    o[0] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], codes32[tid + 3]);
+                    o[1] = make_uint4(codes32[tid + 4], codes32[tid + 5], vlo, vhi);
+                }
+                fill += (uint32_t)__builtin_popcountll(hb);
+            }
         }
     }
     for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);

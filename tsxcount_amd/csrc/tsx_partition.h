@@ -760,10 +760,10 @@ __global__ __launch_bounds__(1024) void desc_prefix_kernel(const unsigned long l
 }
 __global__ __launch_bounds__(256) void desc_pack_kernel(const uint4 *desc, uint64_t desc_cap, const unsigned long long *cnt,
                                                         const unsigned long long *offs, uint32_t nregions, uint4 *out,
-                                                        uint64_t out_cap) {
+                                                        uint64_t out_cap, uint32_t du) {   // du: 16-byte units per description
     for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
-        const uint64_t n = min((uint64_t)cnt[r], desc_cap), o = offs[r];
-        const uint4 *src = desc + (uint64_t)r * desc_cap;
+        const uint64_t n = min((uint64_t)cnt[r], desc_cap) * du, o = offs[r] * du;
+        const uint4 *src = desc + (uint64_t)r * desc_cap * du;
         for (uint64_t i = threadIdx.x; i < n; i += 256)
             if (o + i < out_cap) out[o + i] = src[i];
     }
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                                                             uint32_t nb, uint32_t shift, uint64_t *ovq_all,
                                                             uint32_t *ovq_cnt, uint32_t ovq_cap, uint64_t n_packed,
                                                             uint32_t dst_g0, uint32_t dst_gtot, int own_only,
-                                                            unsigned long long *emit_sum) {
+                                                            unsigned long long *emit_sum, int long_desc) {
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
@@ -926,12 +926,31 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
         const uint32_t nr = n_packed ? (uint32_t)(((uint64_t)r * desc_cap < n_packed) ? min(desc_cap, n_packed - (uint64_t)r * desc_cap) : 0ULL)
                                      : (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
-        const uint4 *rd = desc + (uint64_t)r * desc_cap;
-        uint4 dn = (tid < nr) ? rd[tid] : make_uint4(0, 0, 0, 0);
-        for (uint32_t base = 0; base < nr; base += SP_NT) {
-            const uint4 d = dn;
-            if (base + SP_NT < nr) dn = (base + SP_NT + tid < nr) ? rd[base + SP_NT + tid] : make_uint4(0, 0, 0, 0);   // next batch
-            const uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+        // long descriptions (32 bytes, four strips each; a batch is SP_NT / 4 of them): lanes 4q .. 4q+3 read the same one
+        const uint32_t per = long_desc ? SP_NT / 4 : SP_NT, me = long_desc ? tid >> 2 : tid;
+        const uint4 *rd = desc + (uint64_t)r * desc_cap * (long_desc ? 2u : 1u);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4 dn = z4, dn2 = z4;
+        if (me < nr) { if (long_desc) { dn = rd[2u * me]; dn2 = rd[2u * me + 1u]; } else dn = rd[me]; }
+        for (uint32_t base = 0; base < nr; base += per) {
+            const uint4 d = dn, d2 = dn2;
+            if (base + per < nr) {   // next batch
+                dn = z4; dn2 = z4;
+                if (base + per + me < nr) {
+                    if (long_desc) { dn = rd[2u * (base + per + me)]; dn2 = rd[2u * (base + per + me) + 1u]; }
+                    else dn = rd[base + per + me];
+                }
+            }
+            uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+            if (long_desc) {   // strip t of the four: bases 16 t .. 16 t + 47, validity bits 16 t .. 16 t + 15
+                const uint32_t t = tid & 3u;
+                const uint32_t w0 = d.x, w1 = d.y, w2 = d.z, w3 = d.w, w4 = d2.x, w5 = d2.y;
+                cw0 = (t == 0u) ? w0 : (t == 1u) ? w1 : (t == 2u) ? w2 : w3;
+                cw1 = (t == 0u) ? w1 : (t == 1u) ? w2 : (t == 2u) ? w3 : w4;
+                cw2 = (t == 0u) ? w2 : (t == 1u) ? w3 : (t == 2u) ? w4 : w5;
+                const uint32_t vw = (t < 2u) ? d2.z : d2.w;
+                vm = (vw >> ((t & 1u) * 16u)) & 0xFFFFu;
+            }
             const bool wave_has = __ballot(vm != 0u) != 0ULL;   // only the last batch of a region has idle waves
             uint64_t h = 0;
             uint32_t inc = 0, single = 0;

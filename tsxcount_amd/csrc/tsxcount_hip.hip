@@ -920,7 +920,7 @@ struct ShardOut {
 // split by owner into shard_send (counts per owner to shard_counts), hot keys to `hot`.
 // Sharded run, description exchange: the piece is only DESCRIBED (strip_desc_kernel), the descriptions packed
 // into out[0 .. *count).
-struct DescOut { uint4 *out = nullptr; uint64_t cap = 0; unsigned long long *count = nullptr, *sum = nullptr; };
+struct DescOut { uint4 *out = nullptr; uint64_t cap = 0; unsigned long long *count = nullptr, *sum = nullptr; int long_desc = 0; };
 
 static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
                            hipStream_t st, ShardOut sh = ShardOut(), HotOut hot = HotOut(), DescOut dsc = DescOut()) {
@@ -957,8 +957,9 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     if (dsc.out) {
         const int gdd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8), gdr = gdd * (NT / 64);
-        const uint64_t dcap = ((ntiles + gdd - 1) / gdd) * 64;
-        int rcd = grow(st, m->d_buf[1], m->buf_bytes[1], (size_t)gdr * dcap * 16);
+        const uint32_t du = dsc.long_desc ? 2u : 1u;   // 16-byte units per description (long: four strips in 32 bytes)
+        const uint64_t dcap = ((ntiles + gdd - 1) / gdd) * (dsc.long_desc ? 16 : 64);
+        int rcd = grow(st, m->d_buf[1], m->buf_bytes[1], (size_t)gdr * dcap * du * 16);
         if (rcd != TSX_HIP_OK) return rcd;
         {   // region sizes | region offsets | total
             size_t have = m->desc_cnt_entries;
@@ -968,11 +969,12 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         }
         unsigned long long *d_cnt = m->d_desc_cnt, *d_offs = d_cnt + gdr, *d_tot = d_offs + gdr;
         hipLaunchKernelGGL(strip_desc_kernel, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
-                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum);
+                           (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum, dsc.long_desc);
         hipLaunchKernelGGL(desc_prefix_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long *)d_cnt, (uint32_t)gdr,
                            d_offs, d_tot);
         hipLaunchKernelGGL(desc_pack_kernel, dim3(std::min(gdr, m->cus * 8)), dim3(256), 0, st, (const uint4 *)m->d_buf[1], dcap,
-                           (const unsigned long long *)d_cnt, (const unsigned long long *)d_offs, (uint32_t)gdr, dsc.out, dsc.cap);
+                           (const unsigned long long *)d_cnt, (const unsigned long long *)d_offs, (uint32_t)gdr, dsc.out,
+                           dsc.cap * du, du);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(dsc.count, d_tot, 8, hipMemcpyDeviceToDevice, st));
         if (ev) {   // the walks, level 2 and the build follow in other calls, which record 3..7 of the first window's tuple again
@@ -1051,12 +1053,12 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             rc = grow(st, m->d_buf[0], m->buf_bytes[0], (size_t)gdreg * desc_cap * 16);
             if (rc != TSX_HIP_OK) return rc;
             hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
-                               (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log, (unsigned long long *)nullptr);
+                               (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log, (unsigned long long *)nullptr, 0);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(walk_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
                                (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                                (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr);
+                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, 0);
         } else {
             hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
@@ -1077,7 +1079,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         }
         hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], desc_cap, m->d_desc_cnt,
-                           (unsigned long long *)nullptr);
+                           (unsigned long long *)nullptr, 0);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(walk_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, (const uint4 *)m->d_buf[1], desc_cap,
                            (const unsigned long long *)m->d_desc_cnt, (uint32_t)gdreg, m->dbg, m->d_buf[0], pl.log_cap,
@@ -1358,21 +1360,22 @@ extern "C" int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_ke
 // Instead of sending every key to its owner, every GPU describes its window (tsx_hip_shard_desc_window_device), the
 // descriptions are ALL-GATHERED, and every GPU walks all of them, keeping the keys it owns
 // (tsx_hip_shard_walk_device): N x the rolling work, N/8 of the traffic of the key exchange -- a quarter at N = 2.
-extern "C" int tsx_hip_shard_desc_capacity(tsx_hip_map *m, size_t text_bytes, size_t *descs_out) {
+extern "C" int tsx_hip_shard_desc_capacity(tsx_hip_map *m, size_t text_bytes, int long_desc, size_t *descs_out) {
     if (!m || !descs_out) return TSX_HIP_EINVAL;
-    *descs_out = text_bytes / 16 + 4096;   // one description per 16 start positions at most
+    // one description per 16 (long: 64) start positions at most; a long one is 32 bytes, a short one 16
+    *descs_out = text_bytes / (long_desc ? 64 : 16) + 4096;
     return TSX_HIP_OK;
 }
 
 extern "C" int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off,
-                                                size_t win_len, void *dev_desc, size_t desc_cap, void *dev_count,
-                                                void *dev_kmer_sum, void *stream) {
+                                                size_t win_len, int long_desc, void *dev_desc, size_t desc_cap,
+                                                void *dev_count, void *dev_kmer_sum, void *stream) {
     if (!m || (!dev_text && n_total) || ((uintptr_t)dev_text & 15) || (win_off & 15) || !dev_desc || ((uintptr_t)dev_desc & 15) ||
         !dev_count || win_off > n_total || win_len > n_total - win_off)
         return TSX_HIP_EINVAL;
     if (!tsx_hip_shard_l1_supported(m)) return TSX_HIP_EINVAL;
     if (win_len >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;
-    if (desc_cap < win_len / 16 + 1) return TSX_HIP_ERANGE;
+    if (desc_cap < win_len / (long_desc ? 64 : 16) + 1) return TSX_HIP_ERANGE;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
     if (win_off == 0) HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
@@ -1381,6 +1384,7 @@ extern "C" int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_
     DescOut dsc;
     dsc.out = (uint4 *)dev_desc; dsc.cap = desc_cap; dsc.count = (unsigned long long *)dev_count;
     dsc.sum = (unsigned long long *)dev_kmer_sum;
+    dsc.long_desc = long_desc ? 1 : 0;
     const size_t halo = (size_t)m->p.k - 1;
     const size_t len = std::min(win_len + halo, n_total - win_off);
     return run_fastq_piece(m, (const uint8_t *)dev_text + win_off, len, win_len, win_off ? -1 : 0, st, ShardOut(), HotOut(), dsc);
@@ -1389,8 +1393,8 @@ extern "C" int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_
 // Walks n_desc packed descriptions (any GPU's), keeps the keys this shard owns and partitions them by radix level 1
 // into list set `slot` of `nslots` (slot 0 plans for est_total_keys owned keys in all).  dev_emit_sum += k-mer
 // occurrences kept.  Then tsx_hip_shard_build_l1_device.
-extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, uint32_t slot, uint32_t nslots,
-                                         size_t est_total_keys, void *dev_emit_sum, void *stream) {
+extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, int long_desc, uint32_t slot,
+                                         uint32_t nslots, size_t est_total_keys, void *dev_emit_sum, void *stream) {
     if (!m || (!dev_desc && n_desc) || ((uintptr_t)dev_desc & 15) || nslots == 0 || slot >= nslots) return TSX_HIP_EINVAL;
     if (!tsx_hip_shard_l1_supported(m)) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
@@ -1436,7 +1440,7 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
                        (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                        (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
                        m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
-                       (unsigned long long *)dev_emit_sum);
+                       (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }

@@ -298,11 +298,14 @@ class ShardedCounter:
         nslots = nwin * world   # (windows x sources) list sets; ShardedCounter.__init__ keeps windows * world <= 8, so
                                 # that every walk launch can run two workgroups per CU (level 2 walks <= 4096 pieces per bucket)
         i64 = dict(dtype=torch.int64, device=self.dev)
-        if not hasattr(self, "dsc"):
+        # long descriptions (four strips in 32 bytes: half the bytes per start position) unless TSX_HIP_SHARD_LONG=0
+        lng = 0 if os.environ.get("TSX_HIP_SHARD_LONG", "1") == "0" else 1
+        w8 = 4 if lng else 2      # int64 words per description
+        if getattr(self, "dsc_long", None) != lng:
             cap = ctypes.c_size_t(0)
-            _check(L.tsx_hip_shard_desc_capacity(m.handle, self.win_bytes + 256, ctypes.byref(cap)))
-            self.dsc_cap = cap.value
-            self.dsc = [torch.empty((2 * self.dsc_cap,), **i64) for _ in range(2)]       # 16 B per description
+            _check(L.tsx_hip_shard_desc_capacity(m.handle, self.win_bytes + 256, lng, ctypes.byref(cap)))
+            self.dsc_cap, self.dsc_long = cap.value, lng
+            self.dsc = [torch.empty((w8 * self.dsc_cap,), **i64) for _ in range(2)]
             self.dsc_n = [torch.zeros((1,), **i64) for _ in range(2)]
             self.dsc_all = [torch.zeros((0,), **i64) for _ in range(self.windows)]
             self.emit = torch.zeros((2,), **i64)     # [0] += k-mer occurrences described, [1] += occurrences kept by the walks
@@ -315,7 +318,7 @@ class ShardedCounter:
             b = i & 1
             off = i * self.win_bytes
             ln = max(0, min(self.win_bytes, nbytes - off))
-            rc = L.tsx_hip_shard_desc_window_device(m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln,
+            rc = L.tsx_hip_shard_desc_window_device(m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln, lng,
                                                     vp(self.dsc[b].data_ptr()), self.dsc_cap, vp(self.dsc_n[b].data_ptr()),
                                                     vp(self.emit.data_ptr()), vp(self.cs.cuda_stream))
             self.ev_scan[b].record(self.cs)
@@ -342,18 +345,18 @@ class ShardedCounter:
                     late = late or (i, status)
                     break
                 nmax = max(max(counts), 1)
-                if self.dsc_all[i].numel() < 2 * nmax * world:
-                    self.dsc_all[i] = torch.empty((2 * nmax * world,), **i64)
-                comm.all_gather(self.dsc_all[i][:2 * nmax * world], self.dsc[b][:2 * nmax])
+                if self.dsc_all[i].numel() < w8 * nmax * world:
+                    self.dsc_all[i] = torch.empty((w8 * nmax * world,), **i64)
+                comm.all_gather(self.dsc_all[i][:w8 * nmax * world], self.dsc[b][:w8 * nmax])
                 self.ev_exch[b].record(self.xs)
             total_desc += sum(counts)
             self.cs.wait_event(self.ev_exch[b])
             if i == 0:
-                est_total = int(sum(counts) * 16 * nwin / world * 1.1) + 65536
+                est_total = int(sum(counts) * (64 if lng else 16) * nwin / world * 1.1) + 65536
             for src in range(world):
                 if late is not None:
                     break
-                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.dsc_all[i].data_ptr() + src * nmax * 16), counts[src],
+                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.dsc_all[i].data_ptr() + src * nmax * 8 * w8), counts[src], lng,
                                                  i * world + src, nslots, est_total, vp(self.emit[1:].data_ptr()),
                                                  vp(self.cs.cuda_stream))
                 if rc != OK:
