@@ -36,9 +36,7 @@ for k, l, n_reads, windows, mode in ((31, 17, 240, 3, "auto"), (21, 15, 30, 1, "
     torch.cuda.synchronize()
     for rep in (1, 2):  # second pass merges into segments that already hold data
         sc.step(buf.data_ptr(), len(text))
-        # (the description exchange keeps windows * world <= 8)
-        assert sc.last["key_sum_diff"] == 0 and sc.last["windows"] == min(sc.windows, -(-len(text) // sc.win_bytes))
-        assert sc.windows == windows or sc.last.get("mode") == "desc"
+        assert sc.last["key_sum_diff"] == 0 and sc.last["windows"] == min(windows, -(-len(text) // sc.win_bytes))
         whole = Oracle(k, 21, 4, seed=1)
         whole.count_fastq(synth.fastq(66, 0, n_reads))
         kmers, counts = whole.dump()

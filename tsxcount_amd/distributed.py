@@ -235,8 +235,7 @@ class ShardedCounter:
         if windows is None:
             windows = int(os.environ.get("TSX_HIP_SHARD_WINDOWS", "0")) or max(1, min(4, max_text_bytes // self.MIN_WINDOW))
         self.windows = max(1, int(windows))
-        if self._mode() == "desc":
-            self.windows = max(1, min(self.windows, 8 // self.world))
+
         self.win_bytes = max(4096, ((max_text_bytes + self.windows - 1) // self.windows + 4095) & ~4095)
         cap = ctypes.c_size_t(0)
         _check(hmap._lib.tsx_hip_shard_send_capacity(hmap.handle, self.win_bytes + 256, ctypes.byref(cap)))
@@ -295,8 +294,7 @@ class ShardedCounter:
         m, L, vp = self.m, self.m._lib, ctypes.c_void_p
         world, comm = self.world, self.comm
         nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
-        nslots = nwin * world   # (windows x sources) list sets; ShardedCounter.__init__ keeps windows * world <= 8, so
-                                # that every walk launch can run two workgroups per CU (level 2 walks <= 4096 pieces per bucket)
+        nslots = nwin            # one walk launch (= one set of level-1 lists) per window, over the descriptions of ALL GPUs
         i64 = dict(dtype=torch.int64, device=self.dev)
         # long descriptions (four strips in 32 bytes: half the bytes per start position) unless TSX_HIP_SHARD_LONG=0
         lng = 0 if os.environ.get("TSX_HIP_SHARD_LONG", "1") == "0" else 1
@@ -347,18 +345,19 @@ class ShardedCounter:
                 nmax = max(max(counts), 1)
                 if self.dsc_all[i].numel() < w8 * nmax * world:
                     self.dsc_all[i] = torch.empty((w8 * nmax * world,), **i64)
+                # every GPU sends nmax descriptions: what lies behind its own count is zeroed (validity bits 0 = a strip
+                # without k-mer starts), so that the receivers can walk the gathered array as ONE packed run
+                if counts[self.rank] < nmax:
+                    self.dsc[b][w8 * counts[self.rank]:w8 * nmax].zero_()
                 comm.all_gather(self.dsc_all[i][:w8 * nmax * world], self.dsc[b][:w8 * nmax])
                 self.ev_exch[b].record(self.xs)
             total_desc += sum(counts)
             self.cs.wait_event(self.ev_exch[b])
             if i == 0:
                 est_total = int(sum(counts) * (64 if lng else 16) * nwin / world * 1.1) + 65536
-            for src in range(world):
-                if late is not None:
-                    break
-                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.dsc_all[i].data_ptr() + src * nmax * 8 * w8), counts[src], lng,
-                                                 i * world + src, nslots, est_total, vp(self.emit[1:].data_ptr()),
-                                                 vp(self.cs.cuda_stream))
+            if late is None:
+                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.dsc_all[i].data_ptr()), nmax * world, lng, i, nslots,
+                                                 est_total, vp(self.emit[1:].data_ptr()), vp(self.cs.cuda_stream))
                 if rc != OK:
                     late = (i, [rc])
         self.cs.wait_stream(self.xs)
