@@ -495,6 +495,19 @@ def test_rolling_hash_every_multi_limb_k(T, k):
     m.close()
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_fuzzed_record_structure_two_radix_levels(T, seed, monkeypatch):
+    """The ragged texts through the scan forms of a table split by two radix levels (l = 23): strip descriptions +
+    walk (default) and the one-kernel fused form; k >= 12 keeps 2k >= l + 1 (the slot stores key bits above l)."""
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.integers(12, 33))
+    text = b"".join(_fuzz_text(rng) for _ in range(int(rng.integers(2, 8))))
+    assert_same_as_oracle(T, text, k, 23, 0, path="partitioned")
+    monkeypatch.setenv("TSX_HIP_FUSE", "1")
+    assert_same_as_oracle(T, text, k, 23, 0, path="partitioned")
+    monkeypatch.delenv("TSX_HIP_FUSE")
+
+
 @pytest.mark.parametrize("seed", list(range(24)))
 def test_fuzzed_record_structure_both_paths(T, seed):
     """Strips of 16 start positions, half-strips, tiles of 4 KiB and line ends fall everywhere in
