@@ -274,15 +274,18 @@ class ShardedCounter:
 
     def _mode(self):
         """"keys": every key travels to its owner (8 B per k-mer occurrence, (N-1)/N of them);  "desc": strip
-        descriptions (16 B per up-to-16 occurrences) are all-gathered and every GPU walks all of them, keeping what it
-        owns: N x the rolling work for N/8 of the bytes -- the better deal up to N = 4 (TSX_HIP_SHARD_MODE overrides)."""
+        descriptions (32 B per up-to-64 occurrences) are all-gathered and every GPU walks all of them, keeping what it
+        owns: N x the rolling work (about 1.4 ms per 1e9 positions) for N/16 of the bytes.  At N = 8 that is 3.9 GB
+        received instead of 5.6 GB sent and a step bound by the walks (about 23 ms) rather than by the links; at N = 2
+        a sixth of the bytes over the one link there is.  Default: "desc" wherever the table is split by two radix
+        levels and the keys fit one limb (TSX_HIP_SHARD_MODE overrides)."""
         want = os.environ.get("TSX_HIP_SHARD_MODE", "auto")
         ok = bool(self.m._lib.tsx_hip_shard_l1_supported(self.m.handle))
         if want == "keys" or not ok:
             return "keys"
         if want == "desc":
             return "desc"
-        return "desc" if self.world <= 4 else "keys"
+        return "desc"
 
     def _step_desc(self, text_ptr, nbytes):
         """step() by description exchange.
