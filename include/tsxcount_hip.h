@@ -305,6 +305,10 @@ int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_text, size_
                                      void *stream);
 int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, int long_desc, uint32_t slot,
                               uint32_t nslots, size_t est_total_keys, void *dev_emit_sum, void *stream);
+/* The same result in two kernels (owner-filtered walk into per-wave key logs, then radix level 1 over the logs): the
+ * better form when this GPU keeps few of the keys it walks (world sizes >= 4). */
+int tsx_hip_shard_filter_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, int long_desc, uint32_t slot,
+                                uint32_t nslots, size_t est_total_keys, void *dev_emit_sum, void *stream);
 
 int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
                               void *stream);

@@ -89,6 +89,7 @@ def lib():
     L.tsx_hip_shard_desc_capacity.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(sz)]
     L.tsx_hip_shard_desc_window_device.argtypes = [vp, vp, sz, sz, sz, ctypes.c_int, vp, sz, vp, vp, vp]
     L.tsx_hip_shard_walk_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, sz, vp, vp]
+    L.tsx_hip_shard_filter_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, sz, vp, vp]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None
     L.tsx_hip_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]

@@ -755,7 +755,13 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
 __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
                                                          const unsigned long long *desc_cnt, uint32_t nregions, int dbg,
                                                          uint64_t *log, uint64_t log_cap, unsigned long long *log_cnt,
-                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift) {
+                                                         uint32_t *hist, uint32_t hist_nb, uint32_t hist_shift,
+                                                         uint64_t n_packed, int long_desc, int own_only,
+                                                         unsigned long long *emit_sum) {
+    // Sharded runs at larger world sizes (tsx_hip_shard_filter_device): the descriptions are ONE packed array of n_packed
+    // entries (cut into runs of desc_cap, one per wave), long_desc: four strips per 32-byte entry, own_only: only the keys
+    // this GPU owns are logged (emit_sum += their number).  This GPU keeps one key in N, so what is left of the kernel
+    // is first window + rolls + owner test: without LDS rings it runs at 20 waves per CU.
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
@@ -786,15 +792,40 @@ __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const ui
         if (dbg & 1) return;
         defer_append1(pk, hkey, d);
     };
+    auto is_mine = [&](uint64_t hk) -> bool {
+        if (!own_only) return true;
+        const uint64_t h1[1] = {hk};
+        return owner_shard<1>(p, h1) == p.shard;
+    };
+    unsigned long long emitted = 0;
     lds_barrier();
     for (uint32_t r = region; r < nregions; r += G) {
-        const uint32_t nr = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
-        const uint4 *rd = desc + (uint64_t)r * desc_cap;
-        uint4 dn = ((uint32_t)lane < nr) ? rd[lane] : make_uint4(0, 0, 0, 0);
-        for (uint32_t base = 0; base < nr; base += 64u) {
-            const uint4 d = dn;
-            if (base + 64u < nr) dn = (base + 64u + (uint32_t)lane < nr) ? rd[base + 64u + lane] : make_uint4(0, 0, 0, 0);
-            const uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+        const uint32_t nr = n_packed ? (uint32_t)(((uint64_t)r * desc_cap < n_packed) ? min(desc_cap, n_packed - (uint64_t)r * desc_cap) : 0ULL)
+                                     : (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
+        const uint32_t per = long_desc ? 16u : 64u, me = long_desc ? (uint32_t)lane >> 2 : (uint32_t)lane;
+        const uint4 *rd = desc + (uint64_t)r * desc_cap * (long_desc ? 2u : 1u);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4 dn = z4, dn2 = z4;
+        if (me < nr) { if (long_desc) { dn = rd[2u * me]; dn2 = rd[2u * me + 1u]; } else dn = rd[me]; }
+        for (uint32_t base = 0; base < nr; base += per) {
+            const uint4 d = dn, d2 = dn2;
+            if (base + per < nr) {
+                dn = z4; dn2 = z4;
+                if (base + per + me < nr) {
+                    if (long_desc) { dn = rd[2u * (base + per + me)]; dn2 = rd[2u * (base + per + me) + 1u]; }
+                    else dn = rd[base + per + me];
+                }
+            }
+            uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+            if (long_desc) {   // strip t of the four: bases 16 t .. 16 t + 47, validity bits 16 t .. 16 t + 15
+                const uint32_t t = (uint32_t)lane & 3u;
+                const uint32_t w0 = d.x, w1 = d.y, w2 = d.z, w3 = d.w, w4 = d2.x, w5 = d2.y;
+                cw0 = (t == 0u) ? w0 : (t == 1u) ? w1 : (t == 2u) ? w2 : w3;
+                cw1 = (t == 0u) ? w1 : (t == 1u) ? w2 : (t == 2u) ? w3 : w4;
+                cw2 = (t == 0u) ? w2 : (t == 1u) ? w3 : (t == 2u) ? w4 : w5;
+                const uint32_t vw = (t < 2u) ? d2.z : d2.w;
+                vm = (vw >> ((t & 1u) * 16u)) & 0xFFFFu;
+            }
             uint64_t h = 0;
             if (vm) {
                 const uint64_t x[1] = {((uint64_t)cw0 | ((uint64_t)cw1 << 32)) & p.top_mask};
@@ -844,7 +875,8 @@ __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const ui
                     uint32_t tot = (uint32_t)__popc(hv & y);
                     if (__ballot(tot != 0u) == 0ULL) continue;
                     for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                    if (lane == 0) {
+                    if (lane == 0 && is_mine(s_homh[b])) {
+                            emitted += tot;
                         const uint64_t key = s_homh[b];
                         uint64_t *hkey = s_hot_key + wave * HOT_N;
                         uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
@@ -888,10 +920,11 @@ __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const ui
                 if (fill + 64u * 8u <= cap32) {   // the usual case: the region has room for whatever this half logs
     #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const bool em = (s8 >> j) & 1u;
+                        const bool em = ((s8 >> j) & 1u) && is_mine(hs[j]);
                         const unsigned long long mk = __ballot(em);
                         if (mk) {
                             if (em) {
+                                ++emitted;
                                 const uint64_t key = hs[j];
                                 my_log[fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = key;
                                 atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
@@ -901,10 +934,14 @@ __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const ui
                     }
                 } else {
                     for (int j = 0; j < 8; ++j) {
-                        const bool em = (s8 >> j) & 1u;
+                        uint64_t kj = hs[0];
+#pragma unroll
+                        for (int t = 1; t < 8; ++t) kj = (j == t) ? hs[t] : kj;
+                        const bool em = ((s8 >> j) & 1u) && is_mine(kj);
                         const unsigned long long mk = __ballot(em);
                         if (mk) {
                             if (em) {
+                                ++emitted;
                                 uint64_t key = hs[0];
     #pragma unroll
                                 for (int t = 1; t < 8; ++t) key = (j == t) ? hs[t] : key;
@@ -925,6 +962,10 @@ __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const ui
     }
     lds_barrier();
     if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    if (emit_sum) {
+        for (int d = 32; d > 0; d >>= 1) emitted += __shfl_down(emitted, d, 64);
+        if (lane == 0 && emitted) atomicAdd(emit_sum, emitted);
+    }
     if (lane == 0) log_cnt[region] = min(fill, cap32);   // (k-mers are counted by strip_desc_kernel)
     for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
 }

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                                                             uint32_t nb, uint32_t shift, uint64_t *ovq_all,
                                                             uint32_t *ovq_cnt, uint32_t ovq_cap, uint64_t n_packed,
                                                             uint32_t dst_g0, uint32_t dst_gtot, int own_only,
-                                                            unsigned long long *emit_sum, int long_desc) {
+                                                            unsigned long long *emit_sum, int long_desc, uint32_t flush_q) {
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
@@ -1017,6 +1017,7 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                 }
             }
         }
+            bool waited = false;   // the first flush of a batch waits for the next batch's descriptions
             // ---- the strip in four quarters of 4 positions: roll, append to the rings, flush ----------------------
             for (uint32_t j0 = 0; j0 < 16; j0 += 4) {
                 const uint32_t s4 = (single >> j0) & 0xFu;
@@ -1061,9 +1062,16 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                         }
                     }
                 }
-                lds_barrier();
-                flush(false, j0 == 0);
-                lds_barrier();
+                // A flush per quarter strip keeps the rings safe when every key stays (7 arrive per ring and quarter).  A
+                // GPU of a sharded run keeps one key in N: it flushes every flush_q quarters (N >= 4: once per batch) --
+                // three barriers and a pass over the rings less for each one skipped; a ring that fills up all the same
+                // sends its keys straight to the list.
+                if ((((j0 >> 2) + 1u) % flush_q) == 0u) {
+                    lds_barrier();
+                    flush(false, !waited);
+                    waited = true;
+                    lds_barrier();
+                }
             }
         }
     }

@@ -1058,7 +1058,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             hipLaunchKernelGGL(walk_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
                                (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                                (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, 0);
+                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, 0, 1u);
         } else {
             hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
@@ -1083,7 +1083,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(walk_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, (const uint4 *)m->d_buf[1], desc_cap,
                            (const unsigned long long *)m->d_desc_cnt, (uint32_t)gdreg, m->dbg, m->d_buf[0], pl.log_cap,
-                           pl.c_log, pl.d_hist, hist_nb, hist_shift);
+                           pl.c_log, pl.d_hist, hist_nb, hist_shift, (uint64_t)0, 0, 0, (unsigned long long *)nullptr);
     } else if (p.wk == 1) {
         hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
@@ -1433,6 +1433,10 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     if (n_desc == 0) return TSX_HIP_OK;
     const uint32_t gw = m->sh_rw, nq2 = pl.nb1 * pl.cpr2;
     const uint64_t chunk = (n_desc + gw - 1) / gw;   // descriptions per workgroup
+    // this GPU keeps one key in 2^shard_bits: a ring flush every 1, 2 or 4 quarter strips (walk_part_kernel)
+    const uint32_t nown = 1u << (m->p.lg - m->p.l);
+    uint32_t flush_q = nown >= 4 ? 4u : (nown == 2 ? 2u : 1u);
+    if (const char *e = getenv("TSX_HIP_WALK_FLUSHQ")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) flush_q = (uint32_t)v; }
     TableParams pp = m->p;
     pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
     const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);
@@ -1440,7 +1444,74 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
                        (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                        (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
                        m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
-                       (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0);
+                       (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0, flush_q);
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+// The same in two kernels, for larger world sizes: this GPU keeps one key in N, so the fused walk is mostly waiting
+// for its rolling chains at 16 waves per CU (1.9 ms per 1e9 positions at N = 8).  walk_log_kernel in its owner-filtered
+// form has no rings to hold (20 waves per CU) and logs the kept keys per wave; level 1 of partition_ring_kernel then
+// reads the wave logs as pieces (512 workgroups, each streaming ten of them) into list set `slot` of `nslots`.
+extern "C" int tsx_hip_shard_filter_device(tsx_hip_map *m, const void *dev_desc, size_t n_desc, int long_desc, uint32_t slot,
+                                           uint32_t nslots, size_t est_total_keys, void *dev_emit_sum, void *stream) {
+    if (!m || (!dev_desc && n_desc) || ((uintptr_t)dev_desc & 15) || nslots == 0 || slot >= nslots) return TSX_HIP_EINVAL;
+    if (!tsx_hip_shard_l1_supported(m)) return TSX_HIP_EINVAL;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    if (!m->sh_pl) m->sh_pl = new PartPlan();
+    PartPlan &pl = *m->sh_pl;
+    if (slot == 0) {
+        uint32_t gw = (uint32_t)m->cus * 2;
+        while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * 8) gw /= 2;
+        m->sh_rw = gw;
+        m->sh_windows = nslots;
+        const int g1 = (int)(gw * nslots);
+        const uint64_t maxrec = est_total_keys + 65536;
+        std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
+        std::swap(m->d_cnt, m->sh_cnt); std::swap(m->cnt_entries, m->sh_cnt_entries);
+        int rc = plan_partition(m, maxrec, g1, false, 0, st, pl, g1);
+        std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
+        std::swap(m->d_cnt, m->sh_cnt); std::swap(m->cnt_entries, m->sh_cnt_entries);
+        if (rc != TSX_HIP_OK) return rc;
+        if (!pl.fused) return TSX_HIP_EINVAL;
+        rc = ensure_deferred(m, maxrec, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_def_n, 0, 8, st));
+        const uint32_t nq2 = pl.nb1 * pl.cpr2;
+        rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
+        if (rc != TSX_HIP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(m->d_ovq_cnt, 0, ((size_t)nq2 + pl.G1) * 4, st));
+    } else if (m->sh_windows != nslots || !pl.fused) {
+        return TSX_HIP_EINVAL;
+    }
+    if (slot == 0 && m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
+        HIP_TRY(hipEventRecord(m->ev[(size_t)m->ev_open.front() + 3], st));
+        m->sh_ev3 = true;
+    }
+    if (n_desc == 0) return TSX_HIP_OK;
+    // the wave logs of this slot: the map's own scratch (buffer 0), planned for what this slot may keep
+    const int gs = (int)m->cus * SCAN_WG_PER_CU, greg = gs * (NT / 64);
+    PartPlan lp;
+    const uint64_t keep = est_total_keys / nslots + est_total_keys / nslots / 2 + 65536;
+    int rc = plan_partition(m, keep, greg, true, 0, st, lp, 0);
+    if (rc != TSX_HIP_OK) return rc;
+    TableParams pp = m->p;
+    pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
+    const uint64_t chunk = (n_desc + greg - 1) / greg;   // descriptions per wave
+    hipLaunchKernelGGL(walk_log_kernel, dim3(gs), dim3(NT), m->lut.size() * 8, st, pp, (const uint4 *)dev_desc, chunk,
+                       (const unsigned long long *)nullptr, (uint32_t)greg, m->dbg, m->d_buf[0], lp.log_cap, lp.c_log, lp.d_hist,
+                       lp.nb1, (uint32_t)(m->p.l - lp.b1), (uint64_t)n_desc, long_desc ? 1 : 0, 1,
+                       (unsigned long long *)dev_emit_sum);
+    HIP_TRY(hipGetLastError());
+    const uint32_t gw = m->sh_rw, nq2 = pl.nb1 * pl.cpr2, bits = 5;
+    hipLaunchKernelGGL((partition_ring_kernel<1>), dim3(gw), dim3(RING_NT), (size_t)pl.nb1 * (((size_t)8 << bits) + 36), st, pp,
+                       (const uint64_t *)m->d_buf[0], (const unsigned long long *)nullptr, (const unsigned long long *)nullptr,
+                       (uint64_t)0, 1u, gw, pl.buf1, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr,
+                       pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits, m->dbg,
+                       m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP,
+                       (const unsigned long long *)lp.c_log, (uint32_t)greg, lp.log_cap, 1, (unsigned long long *)nullptr, slot,
+                       nslots);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }

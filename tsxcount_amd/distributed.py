@@ -359,8 +359,12 @@ class ShardedCounter:
             if i == 0:
                 est_total = int(sum(counts) * (64 if lng else 16) * nwin / world * 1.1) + 65536
             if late is None:
-                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.dsc_all[i].data_ptr()), nmax * world, lng, i, nslots,
-                                                 est_total, vp(self.emit[1:].data_ptr()), vp(self.cs.cuda_stream))
+                # a GPU that keeps one key in >= 4: owner-filtered walk into key logs + level 1 (two kernels, no rings to
+                # hold while it mostly rolls); else the fused walk (TSX_HIP_SHARD_FILTER=0|1 overrides)
+                flt = os.environ.get("TSX_HIP_SHARD_FILTER", "auto")
+                walk = L.tsx_hip_shard_filter_device if (flt == "1" or (flt == "auto" and world >= 4)) else L.tsx_hip_shard_walk_device
+                rc = walk(m.handle, vp(self.dsc_all[i].data_ptr()), nmax * world, lng, i, nslots,
+                          est_total, vp(self.emit[1:].data_ptr()), vp(self.cs.cuda_stream))
                 if rc != OK:
                     late = (i, [rc])
         self.cs.wait_stream(self.xs)
