@@ -1531,19 +1531,28 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
 
     // Sizes of the lists of segment `seg`: lane c holds the size of piece c (one load for the wave, not one
     // after the other), seg_total adds them up, my_list picks this wave group's.
+    // list_sizes only LOADS (the low half of the counter; nothing looks at the value, so nothing waits for it, until
+    // seg_total / my_list clamp it to the list capacity where it is used -- for the next segment: when the stream is dry)
+    const uint32_t *cnt32 = reinterpret_cast<const uint32_t *>(list_cnt);
+    const uint32_t cap32 = list_start ? 0xFFFFFFFFu : (uint32_t)min(list_cap, (uint64_t)0xFFFFFFFFu);
     auto list_sizes = [&](uint32_t seg) -> uint32_t {
-        if (list_start) return lane == 0u ? (uint32_t)list_cnt[seg] : 0u;
-        return lane < pieces ? (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + lane], list_cap) : 0u;
+        if (list_start) return lane == 0u ? cnt32[2ull * seg] : 0u;
+        return lane < pieces ? cnt32[2ull * ((uint64_t)seg * pieces + lane)] : 0u;
     };
     auto seg_total = [&](uint32_t c) -> uint32_t {   // pieces <= 8
+        asm volatile("" : "+v"(c));   // (keeps the clamp -- the first look at the loaded value -- down here)
+        c = min(c, cap32);
         c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
         return __builtin_amdgcn_readfirstlane(c);
     };
     auto my_list = [&](uint32_t seg, uint32_t c, const uint64_t *&base) -> uint32_t {
+        asm volatile("" : "+v"(c));
+        c = min(c, cap32);
         if (list_start) { base = lists + (uint64_t)list_start[seg]; return __builtin_amdgcn_readfirstlane(c); }
         base = lists + ((uint64_t)seg * pieces + grp) * list_cap;
         return __builtin_amdgcn_readlane(c, grp);
     };
+
 
     uint64_t B[BK];
     uint32_t pf = 0;   // the dword this lane prefetched for the next segment
