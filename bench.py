@@ -311,7 +311,10 @@ def main():
             # description exchange: "scan" = strip_desc_kernel + pack of every window, "level1" = the walks over the
             # descriptions of all GPUs (with the later windows' descriptions interleaved), then level 2 and the build
             names["scan"] = "strip_desc_kernel + desc_pack_kernel"
-            names["level1"] = "walk_part_kernel (descriptions of all %d GPUs)" % world
+            flt = os.environ.get("TSX_HIP_SHARD_FILTER", "auto")
+            names["level1"] = ("%s (descriptions of all %d GPUs)"
+                               % ("walk_log_kernel with owner filter + partition_ring_kernel (level 1)"
+                                  if (flt == "1" or (flt == "auto" and world >= 4)) else "walk_part_kernel", world))
             stage_bytes["scan"] = nbytes + nbytes // 2 * 2          # text read; descriptions written and packed
             stage_bytes["level1"] = world * (nbytes // 2) + rec_b * keys_logged
         stage_ms = {k2: stage[k2] / pieces for k2 in names}
