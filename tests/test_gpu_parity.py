@@ -348,15 +348,19 @@ def test_fused_scan_sub_list_overflow(T, monkeypatch):
     monkeypatch.delenv("TSX_HIP_FUSE")
 
 
-@pytest.mark.parametrize("fuse", ["2", "1", "0"])
+@pytest.mark.parametrize("fuse", ["2", "2L", "1", "0"])
 def test_fused_and_unfused_scan_agree_entry_for_entry(T, monkeypatch, fuse):
     """Two radix levels, pieces of the host entry point (segments rebuilt from their previous content): the three
     forms of the scan (2: strip descriptions + walk, 1: one fused kernel, 0: key log + level 1) leave the same table."""
     from tsxcount_amd import synth
+    if fuse == "2L":   # the two-kernel form with four strips per description
+        monkeypatch.setenv("TSX_HIP_LOCAL_LONG", "1")
+        fuse = "2"
     monkeypatch.setenv("TSX_HIP_FUSE", fuse)
     monkeypatch.setenv("TSX_HIP_PIECE_BYTES", "300000")
     text = synth.fastq(33, 0, 5000)
     assert_same_as_oracle(T, text, 27, 24, 0, path="partitioned")
+    monkeypatch.delenv("TSX_HIP_LOCAL_LONG", raising=False)
     monkeypatch.delenv("TSX_HIP_PIECE_BYTES")
     monkeypatch.delenv("TSX_HIP_FUSE")
 
@@ -938,7 +942,7 @@ def test_config5_k127_load_0p8_overflow_merge(world):
         assert "MERGE OK" in o
 
 
-@pytest.mark.parametrize("l,mode", [(16, "auto"), (23, "keys"), (23, "desc"), (23, "desc16")])
+@pytest.mark.parametrize("l,mode", [(16, "auto"), (23, "keys"), (23, "desc"), (23, "desc16"), (23, "desc_walk")])
 def test_sharded_counting_world_8_in_one_process(T, monkeypatch, l, mode):
     """(l = 23: a table split by two radix levels -- "keys": level 1 window by window as the keys arrive, "desc": strip
     descriptions all-gathered, every shard walks all of them and keeps what it owns.)
@@ -954,6 +958,9 @@ def test_sharded_counting_world_8_in_one_process(T, monkeypatch, l, mode):
     from tsxcount_amd import synth
     if mode == "desc16":   # one strip per description (16 bytes) instead of four (32 bytes)
         monkeypatch.setenv("TSX_HIP_SHARD_LONG", "0")
+        mode = "desc"
+    if mode == "desc_walk":   # the fused walk (a ring flush per batch at this world size) instead of the filtered key log
+        monkeypatch.setenv("TSX_HIP_SHARD_FILTER", "0")
         mode = "desc"
     monkeypatch.setenv("TSX_HIP_SHARD_MODE", mode)
     world, k, n_reads = 8, 31, 400
