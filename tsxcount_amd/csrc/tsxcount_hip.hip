@@ -692,6 +692,10 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
     pl.nseg = 1u << nsegbits;
     // fan-out per level is capped at 512 (histogram of the scan kernel and ring staging live in LDS)
     pl.b1 = std::min(9, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
+    if (const char *e = getenv("TSX_HIP_B1")) {   // experiments: the split between the two levels
+        const int b = atoi(e);
+        if (b >= 1 && b <= 9 && nsegbits - b >= 1 && nsegbits - b <= 9) pl.b1 = b;
+    }
     pl.b2 = nsegbits - pl.b1;
     pl.nb1 = 1u << pl.b1; pl.nb2 = 1u << pl.b2;
     pl.hist_nb = hist_nb_override ? hist_nb_override : pl.nb1;
@@ -867,9 +871,14 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
             if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
                 hipLaunchKernelGGL((build_segments_stream_kernel<true>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
                                    lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_pf, build_la);
-            else
-                hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
+            else {
+                // TSX_HIP_BUILD_SNT: threads per workgroup of the stream build (1024; 512 with TSX_HIP_SEG_BITS=13 puts two
+                // workgroups on a CU: 64 KiB segment + 16 KiB of rings each)
+                int snt = 1024;
+                if (const char *e = getenv("TSX_HIP_BUILD_SNT")) snt = std::min(1024, std::max(64 * (int)pieces, atoi(e) & ~63));
+                hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(snt), seg_bytes + (size_t)(snt / 64) * 2048, st, pp,
                                    lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_pf, build_la);
+            }
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
                                lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
