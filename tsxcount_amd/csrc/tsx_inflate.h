@@ -22,7 +22,7 @@ constexpr int INF_NT = 64;         // one wave; lane = member
 constexpr int INF_MAXBITS = 15;
 constexpr int INF_LCODES = 288, INF_DCODES = 30;
 
-constexpr size_t INF_LDS_BYTES = 256 * 4 + (size_t)(2 * (INF_MAXBITS + 1) + INF_LCODES + INF_DCODES) * INF_NT * 2 +
+constexpr size_t INF_LDS_BYTES = 8 * 256 * 4 + (size_t)(2 * (INF_MAXBITS + 1) + INF_LCODES + INF_DCODES) * INF_NT * 2 +
                                  (size_t)(INF_LCODES + INF_DCODES + 2) * INF_NT;
 
 enum InflateStatus : uint32_t {
@@ -30,32 +30,40 @@ enum InflateStatus : uint32_t {
     INF_EOUTPUT = 6, INF_ESIZE = 7, INF_ECRC = 8
 };
 
-// LSB-first bit reader over [p, end) (RFC 1951 section 3.1.1); four bytes per refill where they exist
+// LSB-first bit reader (RFC 1951 section 3.1.1), four bytes per refill.  The word a refill shifts in was loaded by
+// the refill BEFORE it: a load that is waited for where it is issued costs the lane a memory round trip every 32 bits
+// (every second match).  So the reader runs up to 8 bytes past the member's data (the caller pads the buffer: the
+// bytes are the member's trailer and the next member); `avail` counts the bits that really belong to the member, a
+// read beyond them fails as a truncated stream does.
 struct InfBits {
-    const uint8_t *p, *end;
+    const uint8_t *p;     // the next word to load
     uint64_t buf;
-    uint32_t cnt;
+    uint32_t cnt, nxt, avail;
     bool fail;
+    __device__ __forceinline__ void init(const uint8_t *start, uint32_t nbytes) {
+        p = start + 4;
+        buf = 0; cnt = 0; fail = false;
+        avail = nbytes * 8u;
+        __builtin_memcpy(&nxt, start, 4);
+    }
     __device__ __forceinline__ void refill() {
         if (cnt <= 32u) {
-            if (p + 4 <= end) {
-                uint32_t w;
-                __builtin_memcpy(&w, p, 4);
-                buf |= (uint64_t)w << cnt;
-                cnt += 32u;
-                p += 4;
-            } else {
-                while (cnt <= 56u && p < end) { buf |= (uint64_t)(*p++) << cnt; cnt += 8u; }
-            }
+            buf |= (uint64_t)nxt << cnt;
+            cnt += 32u;
+            __builtin_memcpy(&nxt, p, 4);
+            p += 4;
         }
+    }
+    __device__ __forceinline__ void used(uint32_t n) {   // n bits of buf consumed
+        if (n > avail) { fail = true; avail = 0; } else avail -= n;
     }
     __device__ __forceinline__ uint32_t get(uint32_t n) {   // n <= 16
         refill();
-        if (cnt < n) { fail = true; return 0; }
         const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
         buf >>= n;
         cnt -= n;
-        return v;
+        used(n);
+        return fail ? 0u : v;
     }
 };
 
@@ -65,40 +73,42 @@ struct InfCode {
     uint16_t *count, *symbol;
 };
 
-// The 16 counts of a code, two per register: the decode loop below is unrolled, so they stay in registers and a
-// symbol costs ONE LDS read (the symbol itself) instead of one per bit of its code.
-struct InfCounts { uint32_t w[8]; };
-__device__ __forceinline__ InfCounts inf_counts(const InfCode &h) {
-    InfCounts c;
+// Decoding without a loop over the bits.  In a canonical code the codes of length len are the integers
+// first[len] .. first[len] + count[len] - 1, first[len + 1] = (first[len] + count[len]) << 1 (RFC 1951 section 3.2.2).
+// Read the next 15 stream bits as a 15-bit number v with the FIRST bit on top: a code of length len is a prefix of v
+// exactly when v < lim[len] = (first[len] + count[len]) << (15 - len) and v >= lim[len - 1].  The lim[] do not fall,
+// so the length of the code in front is 1 + the number of lim[] that v has reached: fifteen independent compares on
+// registers instead of fifteen rounds of shift / compare / branch in which every lane of the wave leaves at another
+// round.  The symbol is symbol[(v >> (15 - len)) + delta[len]], delta[len] = (symbols with shorter codes) - first[len].
+struct InfFast { uint32_t lim[INF_MAXBITS]; };
+// Builds lim[] in registers from the counts inf_construct left in LDS and overwrites count[1..15] with delta[].
+__device__ __forceinline__ InfFast inf_fast(const InfCode &h) {
+    InfFast f;
+    uint32_t first = 0, index = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) c.w[i] = (uint32_t)h.count[(2 * i) * INF_NT] | ((uint32_t)h.count[(2 * i + 1) * INF_NT] << 16);
-    return c;
-}
-
-// Decode one symbol, bit by bit (at most 15 steps): the codes of one length are consecutive integers, the
-// first code of length len+1 is (first code of len + count[len]) << 1 (RFC 1951 section 3.2.2).
-__device__ __forceinline__ int inf_decode(InfBits &b, const InfCode &h, const InfCounts &c) {
-    b.refill();
-    uint32_t code = 0, first = 0, index = 0;
-    uint64_t bits = b.buf;
-    uint32_t left = b.cnt;
-#pragma unroll
-    for (uint32_t len = 1; len <= (uint32_t)INF_MAXBITS; ++len) {
-        if (left == 0) { b.fail = true; return -1; }
-        code |= (uint32_t)bits & 1u;
-        bits >>= 1;
-        --left;
-        const uint32_t count = (c.w[len >> 1] >> ((len & 1u) * 16u)) & 0xFFFFu;
-        if (code < first + count) {
-            b.buf = bits;
-            b.cnt = left;
-            return (int)h.symbol[(index + (code - first)) * INF_NT];
-        }
+    for (int len = 1; len <= INF_MAXBITS; ++len) {
+        const uint32_t count = h.count[len * INF_NT];
+        f.lim[len - 1] = (first + count) << (INF_MAXBITS - len);
+        h.count[len * INF_NT] = (uint16_t)(index - first);
         index += count;
         first = (first + count) << 1;
-        code <<= 1;
     }
-    return -1;
+    return f;
+}
+__device__ __forceinline__ int inf_decode(InfBits &b, const InfCode &h, const InfFast &f) {
+    b.refill();   // >= 33 bits in buf
+    const uint32_t v = __brev((uint32_t)b.buf) >> (32 - INF_MAXBITS);
+    uint32_t n = 0;
+#pragma unroll
+    for (int len = 1; len <= INF_MAXBITS; ++len) n += (v >= f.lim[len - 1]) ? 1u : 0u;
+    if (n >= (uint32_t)INF_MAXBITS) return -1;   // no code starts like this (an incomplete code)
+    const uint32_t len = n + 1u;
+    const uint32_t idx = ((v >> (INF_MAXBITS - len)) + (uint32_t)h.count[len * INF_NT]) & 0xFFFFu;
+    b.buf >>= len;
+    b.cnt -= len;
+    b.used(len);
+    if (b.fail) return -1;
+    return (int)h.symbol[idx * INF_NT];
 }
 
 // Build count[]/symbol[] from n code lengths (lengths[i * INF_NT]).  Returns < 0 for an over-subscribed set,
@@ -130,15 +140,6 @@ __device__ inline int inf_construct(const InfCode &h, const uint8_t *lengths, in
     return left;
 }
 
-__device__ __constant__ const uint16_t INF_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
-                                                         35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ const uint8_t INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
-                                                       3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ const uint16_t INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193,
-                                                         257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
-                                                         8193, 12289, 16385, 24577};
-__device__ __constant__ const uint8_t INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
-                                                       7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ __constant__ const uint8_t INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // One member per lane.  in_off/in_len: the raw deflate data of member i inside gz; out_off/out_len: where its
@@ -150,22 +151,20 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
                                                                  const uint32_t *crc_table) {
     extern __shared__ uint32_t s_inf[];   // INF_LDS_BYTES: CRC table | count and symbol tables of both codes | code lengths
     uint32_t *s_crc = s_inf;
-    uint16_t *s_lcount = reinterpret_cast<uint16_t *>(s_crc + 256);
+    uint16_t *s_lcount = reinterpret_cast<uint16_t *>(s_crc + 8 * 256);
     uint16_t *s_lsym = s_lcount + (INF_MAXBITS + 1) * INF_NT;
     uint16_t *s_dcount = s_lsym + INF_LCODES * INF_NT;
     uint16_t *s_dsym = s_dcount + (INF_MAXBITS + 1) * INF_NT;
     uint8_t *s_len = reinterpret_cast<uint8_t *>(s_dsym + INF_DCODES * INF_NT);
     const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < 256; i += INF_NT) s_crc[i] = crc_table[i];
+    for (uint32_t i = lane; i < 8 * 256; i += INF_NT) s_crc[i] = crc_table[i];
     __syncthreads();
     const uint32_t mem = blockIdx.x * INF_NT + lane;
     if (mem >= nmem) return;
     const InfCode lc = {s_lcount + lane, s_lsym + lane}, dc = {s_dcount + lane, s_dsym + lane};
     uint8_t *lengths = s_len + lane;
     InfBits b;
-    b.p = gz + in_off[mem];
-    b.end = b.p + in_len[mem];
-    b.buf = 0; b.cnt = 0; b.fail = false;
+    b.init(gz + in_off[mem], in_len[mem]);
     uint8_t *o = out + out_off[mem];
     const uint32_t olen = out_len[mem];
     uint32_t pos = 0, err = INF_OK;
@@ -177,6 +176,7 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
         const uint32_t type = b.get(2);
         if (b.fail) { err = INF_ETRUNC; break; }
         if (type == 0) {   // stored: skip to the byte boundary, LEN, NLEN, LEN bytes
+            b.used(b.cnt & 7u);
             b.buf >>= (b.cnt & 7u);
             b.cnt &= ~7u;
             const uint32_t len = b.get(16), nlen = b.get(16);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
             for (uint32_t i = 0; i < 19; ++i) lengths[(uint32_t)INF_CLORDER[i] * INF_NT] = (i < ncode) ? (uint8_t)b.get(3) : 0;
             if (b.fail) { err = INF_ETRUNC; break; }
             if (inf_construct(lc, lengths, 19) != 0) { err = INF_ELENGTHS; break; }   // the code-length code must be complete
-            const InfCounts cc = inf_counts(lc);
+            const InfFast cc = inf_fast(lc);
             uint32_t idx = 0;
             while (idx < nlen + ndist && err == INF_OK) {
                 const int sym = inf_decode(b, lc, cc);
@@ -232,60 +232,115 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
             const int rd = inf_construct(dc, lengths + nlen * INF_NT, (int)ndist);
             if (rd < 0 || (rd > 0 && ndist - (uint32_t)dc.count[0] != 1)) { err = INF_ELENGTHS; break; }
         }
-        // ---- the compressed data of the block
-        const InfCounts lcn = inf_counts(lc), dcn = inf_counts(dc);
+        // ---- the compressed data of the block.
+        // The 64 lanes of the wave are at 64 different places of 64 different streams, and the wave pays for every
+        // path any of its lanes takes: with "decode a symbol, then copy the whole match" an iteration cost the
+        // longest copy loop among the lanes plus every special case some lane was in (about five memory round trips
+        // per symbol).  So a lane is in one of two states -- it decodes a symbol, or it has `clen` bytes of a match
+        // left to copy -- and an iteration of the wave is ONE decode for the lanes of the first kind followed by ONE
+        // copy step (one load round trip at most) for the lanes of the second.
+        const InfFast lcn = inf_fast(lc), dcn = inf_fast(dc);
+        uint32_t clen = 0, cdist = 0;
+        uint64_t pat = 0;   // distances below 8: the bytes to repeat, replicated to 8 bytes
         for (;;) {
             if (budget-- == 0) { err = INF_EOUTPUT; break; }
-            const int sym = inf_decode(b, lc, lcn);
-            if (sym < 0) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
-            if (sym < 256) {
-                if (pos >= olen) { err = INF_EOUTPUT; break; }
-                o[pos++] = (uint8_t)sym;
-                continue;
-            }
-            if (sym == 256) break;
-            const uint32_t ls = (uint32_t)sym - 257u;
-            if (ls >= 29u) { err = INF_ESYMBOL; break; }
-            const uint32_t len = (uint32_t)INF_LBASE[ls] + b.get(INF_LEXT[ls]);
-            const int ds = inf_decode(b, dc, dcn);
-            if (ds < 0 || ds >= INF_DCODES) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
-            const uint32_t dist = (uint32_t)INF_DBASE[ds] + b.get(INF_DEXT[ds]);
-            if (b.fail) { err = INF_ETRUNC; break; }
-            if (dist > pos || pos + len > olen) { err = INF_EOUTPUT; break; }
-            // The copy, eight bytes at a time: a byte-wise `o[pos] = o[pos - dist]` makes every byte wait for the store
-            // before it (same-thread load after store: ~2.7 us per byte measured, the whole inflate).  ONE unaligned
-            // 8-byte load of the source; distances below 8 repeat: the first `dist` bytes are replicated into a
-            // pattern of the largest multiple of dist that fits 8 bytes.  Wide stores may run up to 7 bytes past the
-            // match -- bytes of this member that later output overwrites -- so they stop 8 bytes before its end.
-            const uint32_t stop = pos + len;
-            if (dist >= 8u) {
-                while (pos + 8u <= stop) {
-                    uint64_t w;
-                    __builtin_memcpy(&w, o + pos - dist, 8);
-                    __builtin_memcpy(o + pos, &w, 8);
-                    pos += 8u;
+            if (clen == 0) {
+                const int sym = inf_decode(b, lc, lcn);
+                if (sym < 0) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
+                if (sym < 256) {
+                    if (pos >= olen) { err = INF_EOUTPUT; break; }
+                    o[pos++] = (uint8_t)sym;
+                    continue;
                 }
-                if (pos < stop && pos + 8u <= olen) {   // the tail in one more wide copy
-                    uint64_t w;
-                    __builtin_memcpy(&w, o + pos - dist, 8);
-                    __builtin_memcpy(o + pos, &w, 8);
-                    pos = stop;
+                if (sym == 256) break;
+                const uint32_t ls = (uint32_t)sym - 257u;
+                if (ls >= 29u) { err = INF_ESYMBOL; break; }
+                // base and extra bits of a length / distance symbol by arithmetic (RFC 1951 section 3.2.5: after the
+                // first eight lengths / four distances the number of extra bits grows by one every four / two symbols)
+                // -- a lookup in a table in memory is a load the next step waits for, twice per match
+                uint32_t lext = 0, lbase = 3u + ls;
+                if (ls >= 8u) { lext = (ls - 4u) >> 2; lbase = 3u + ((4u + (ls & 3u)) << lext); }
+                if (ls == 28u) { lext = 0; lbase = 258u; }
+                const uint32_t len = lbase + b.get(lext);
+                const int ds = inf_decode(b, dc, dcn);
+                if (ds < 0 || ds >= INF_DCODES) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
+                uint32_t dext = 0, dbase = 1u + (uint32_t)ds;
+                if (ds >= 4) { dext = ((uint32_t)ds - 2u) >> 1; dbase = 1u + ((2u + ((uint32_t)ds & 1u)) << dext); }
+                const uint32_t dist = dbase + b.get(dext);
+                if (b.fail) { err = INF_ETRUNC; break; }
+                if (dist > pos || pos + len > olen) { err = INF_EOUTPUT; break; }
+                clen = len;
+                cdist = dist;
+                if (dist < 8u) {   // the last `dist` bytes of the output, replicated: byte j of pat = pattern[j mod dist]
+                    uint64_t w = 0;
+                    if (pos >= 8u) {
+                        __builtin_memcpy(&w, o + pos - 8u, 8);
+                        w >>= 8u * (8u - dist);
+                    } else {
+                        for (uint32_t i = 0; i < dist; ++i) w |= (uint64_t)o[pos - dist + i] << (8u * i);
+                    }
+                    for (uint32_t have = dist; have < 8u; have *= 2u) w |= w << (8u * have);
+                    pat = w;
                 }
-            } else if (stop + 8u <= olen) {
-                uint64_t w = 0;
-                for (uint32_t i = 0; i < dist; ++i) w |= (uint64_t)o[pos - dist + i] << (8u * i);
-                for (uint32_t have = dist; have < 8u; have *= 2u) w |= w << (8u * have);   // byte j = pattern[j mod dist]
-                const uint32_t step = (8u / dist) * dist;
-                for (; pos < stop; pos += step) __builtin_memcpy(o + pos, &w, 8);
-                pos = stop;
             }
-            for (; pos < stop; ++pos) o[pos] = o[pos - dist];
+            // ---- one copy step.  A byte-wise `o[pos] = o[pos - dist]` makes every byte wait for the store before it;
+            // the steps are 8 bytes wide.  Wide stores may run up to 7 bytes past the match -- bytes of this member
+            // that later output overwrites -- so they are used while 8 bytes (64 for a pattern: 7 steps + 8) remain in the member.
+            if (cdist < 8u) {
+                const uint32_t step = (8u / cdist) * cdist;   // whole periods per store
+                if (pos + 64u <= olen) {                     // up to eight stores, no load: long runs in few iterations
+                    const uint32_t n = min(clen, 8u * step);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8u; ++j)
+                        if (j * step < n) __builtin_memcpy(o + pos + j * step, &pat, 8);
+                    pos += n;
+                    clen -= n;
+                } else {
+                    for (; clen; --clen, ++pos) o[pos] = o[pos - cdist];
+                }
+            } else if (cdist >= 32u && clen >= 32u) {   // source and destination of a 32-byte step cannot overlap
+                uint64_t w[4];
+                __builtin_memcpy(w, o + pos - cdist, 32);
+                __builtin_memcpy(o + pos, w, 32);
+                pos += 32u;
+                clen -= 32u;
+            } else if (pos + 8u <= olen) {
+                uint64_t w;
+                __builtin_memcpy(&w, o + pos - cdist, 8);
+                __builtin_memcpy(o + pos, &w, 8);
+                const uint32_t n = min(clen, 8u);
+                pos += n;
+                clen -= n;
+            } else {
+                for (; clen; --clen, ++pos) o[pos] = o[pos - cdist];
+            }
         }
     }
     if (err == INF_OK && pos != olen) err = INF_ESIZE;
-    if (err == INF_OK) {   // CRC-32 of the member (gzip trailer), byte by byte through the LDS copy of the table
-        uint32_t c = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < olen; ++i) c = s_crc[(c ^ o[i]) & 0xFFu] ^ (c >> 8);
+    if (err == INF_OK) {
+        // CRC-32 of the member (gzip trailer).  Byte by byte -- load, look up, xor, each waiting for the one before --
+        // this was most of the kernel (a memory round trip per byte).  Eight bytes per step instead: the text comes
+        // back 32 bytes per load with the next 32 already on their way, and the eight table lookups of a step
+        // (tables for a byte followed by 0..7 zero bytes) do not depend on each other.
+        uint32_t c = 0xFFFFFFFFu, i = 0;
+        auto step8 = [&](uint64_t w) {
+            const uint32_t lo = (uint32_t)w ^ c, hi = (uint32_t)(w >> 32);
+            c = s_crc[7 * 256 + (lo & 0xFFu)] ^ s_crc[6 * 256 + ((lo >> 8) & 0xFFu)] ^ s_crc[5 * 256 + ((lo >> 16) & 0xFFu)] ^
+                s_crc[4 * 256 + (lo >> 24)] ^ s_crc[3 * 256 + (hi & 0xFFu)] ^ s_crc[2 * 256 + ((hi >> 8) & 0xFFu)] ^
+                s_crc[1 * 256 + ((hi >> 16) & 0xFFu)] ^ s_crc[hi >> 24];
+        };
+        if (olen >= 32u) {
+            uint64_t w[4], nx[4];
+            __builtin_memcpy(nx, o, 32);
+            for (; i + 32u <= olen; i += 32u) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = nx[j];
+                if (i + 64u <= olen) __builtin_memcpy(nx, o + i + 32u, 32);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) step8(w[j]);
+            }
+        }
+        for (; i < olen; ++i) c = s_crc[(c ^ o[i]) & 0xFFu] ^ (c >> 8);
         if ((c ^ 0xFFFFFFFFu) != crc[mem]) err = INF_ECRC;
     }
     status[mem] = err;

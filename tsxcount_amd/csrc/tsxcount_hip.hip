@@ -6,6 +6,7 @@
 #include "tsx_partition.h"
 #include "tsx_inflate.h"
 
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1709,14 +1710,21 @@ static int inflate_bgzf_to_device(const uint8_t *gz, size_t n, hipStream_t st, u
     if (!bgzf_index(gz, n, ix)) { g_last_error = "not a BGZF file (no BC extra field in every gzip member)"; return TSX_HIP_EINVAL; }
     const size_t nm = ix.in_off.size();
     uint8_t *d_gz = nullptr, *d_out = nullptr, *d_ix = nullptr;
-    uint32_t crc_tab[256];
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t c = i;
-        for (int b = 0; b < 8; ++b) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        crc_tab[i] = c;
-    }
-    // one allocation for the index: in_off | out_off | in_len | out_len | crc | status | crc table
-    const size_t ix_bytes = nm * (8 + 8 + 4 + 4 + 4 + 4) + 1024;
+    // CRC-32 tables for eight bytes per step: crc_tab[j][v] = CRC of byte v followed by j zero bytes
+    static uint32_t crc_tab[8 * 256];
+    static std::once_flag crc_once;
+    std::call_once(crc_once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int b = 0; b < 8; ++b) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_tab[i] = c;
+        }
+        for (int j = 1; j < 8; ++j)
+            for (uint32_t i = 0; i < 256; ++i)
+                crc_tab[j * 256 + i] = (crc_tab[(j - 1) * 256 + i] >> 8) ^ crc_tab[crc_tab[(j - 1) * 256 + i] & 0xFFu];
+    });
+    // one allocation for the index: in_off | out_off | in_len | out_len | crc | status | crc tables
+    const size_t ix_bytes = nm * (8 + 8 + 4 + 4 + 4 + 4) + sizeof(crc_tab);
     auto cleanup = [&]() { (void)hipFree(d_gz); (void)hipFree(d_ix); };
 #define HIP_TRY_I(expr)                                                                             \
     do {                                                                                            \
@@ -1739,7 +1747,7 @@ static int inflate_bgzf_to_device(const uint8_t *gz, size_t n, hipStream_t st, u
     HIP_TRY_I(hipMemcpyAsync(d_in_len, ix.in_len.data(), nm * 4, hipMemcpyHostToDevice, st));
     HIP_TRY_I(hipMemcpyAsync(d_out_len, ix.out_len.data(), nm * 4, hipMemcpyHostToDevice, st));
     HIP_TRY_I(hipMemcpyAsync(d_crc, ix.crc.data(), nm * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_tab, crc_tab, 1024, hipMemcpyHostToDevice, st));
+    HIP_TRY_I(hipMemcpyAsync(d_tab, crc_tab, sizeof(crc_tab), hipMemcpyHostToDevice, st));
     HIP_TRY_I(hipMemsetAsync(d_status, 0xFF, nm * 4, st));
     HIP_TRY_I(hipMemsetAsync(d_out + ix.text_bytes, '\n', 256, st));
     HIP_TRY_I(hipFuncSetAttribute((const void *)inflate_members_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
