@@ -30,35 +30,38 @@ enum InflateStatus : uint32_t {
     INF_EOUTPUT = 6, INF_ESIZE = 7, INF_ECRC = 8
 };
 
-// LSB-first bit reader (RFC 1951 section 3.1.1), four bytes per refill.  The word a refill shifts in was loaded by
-// the refill BEFORE it: a load that is waited for where it is issued costs the lane a memory round trip every 32 bits
-// (every second match).  So the reader runs up to 8 bytes past the member's data (the caller pads the buffer: the
-// bytes are the member's trailer and the next member); `avail` counts the bits that really belong to the member, a
-// read beyond them fails as a truncated stream does.
+// LSB-first bit reader (RFC 1951 section 3.1.1).  refill() tops the 64-bit buffer up to 56..63 bits from the eight
+// bytes at p and moves p by the whole bytes that fitted (the rest is read again next time: or-ing the same bits in
+// twice does no harm).  The eight bytes were loaded by the refill BEFORE: s_waitcnt counts per wave, not per lane, so
+// a load that is waited for where it is issued -- or at the next of several refill sites -- costs all 64 lanes a
+// memory round trip each time.  One refill at the top of an iteration covers the iteration (a match takes at most
+// 15 + 5 + 15 + 13 = 48 bits); get() and the decoder refill only when fewer than 32 bits are left (block headers,
+// stored blocks).  The reader runs up to 8 bytes past the member's data (the caller pads the buffer); `avail` counts
+// the bits that belong to the member, a read beyond them fails as a truncated stream does.
 struct InfBits {
-    const uint8_t *p;     // the next word to load
-    uint64_t buf;
-    uint32_t cnt, nxt, avail;
+    const uint8_t *p;     // the first byte not (completely) in buf
+    uint64_t buf, nxt;    // nxt: the eight bytes at p
+    uint32_t cnt, avail;
     bool fail;
     __device__ __forceinline__ void init(const uint8_t *start, uint32_t nbytes) {
-        p = start + 4;
+        p = start;
         buf = 0; cnt = 0; fail = false;
         avail = nbytes * 8u;
-        __builtin_memcpy(&nxt, start, 4);
+        __builtin_memcpy(&nxt, p, 8);
     }
     __device__ __forceinline__ void refill() {
-        if (cnt <= 32u) {
-            buf |= (uint64_t)nxt << cnt;
-            cnt += 32u;
-            __builtin_memcpy(&nxt, p, 4);
-            p += 4;
-        }
+        buf |= nxt << cnt;
+        const uint32_t adv = (63u - cnt) >> 3;
+        p += adv;
+        cnt += adv * 8u;
+        __builtin_memcpy(&nxt, p, 8);
     }
+    __device__ __forceinline__ void need32() { if (cnt < 32u) refill(); }
     __device__ __forceinline__ void used(uint32_t n) {   // n bits of buf consumed
         if (n > avail) { fail = true; avail = 0; } else avail -= n;
     }
     __device__ __forceinline__ uint32_t get(uint32_t n) {   // n <= 16
-        refill();
+        need32();
         const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
         buf >>= n;
         cnt -= n;
@@ -96,7 +99,7 @@ __device__ __forceinline__ InfFast inf_fast(const InfCode &h) {
     return f;
 }
 __device__ __forceinline__ int inf_decode(InfBits &b, const InfCode &h, const InfFast &f) {
-    b.refill();   // >= 33 bits in buf
+    b.need32();
     const uint32_t v = __brev((uint32_t)b.buf) >> (32 - INF_MAXBITS);
     uint32_t n = 0;
 #pragma unroll
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
         for (;;) {
             if (budget-- == 0) { err = INF_EOUTPUT; break; }
             if (clen == 0) {
+                b.refill();   // the one refill of the iteration: >= 56 bits
                 const int sym = inf_decode(b, lc, lcn);
                 if (sym < 0) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
                 if (sym < 256) {

@@ -1735,7 +1735,7 @@ static int inflate_bgzf_to_device(const uint8_t *gz, size_t n, hipStream_t st, u
             return (_e == hipErrorOutOfMemory) ? TSX_HIP_ENOMEM : TSX_HIP_EHIP;                     \
         }                                                                                           \
     } while (0)
-    HIP_TRY_I(hipMalloc((void **)&d_gz, n + 16));
+    HIP_TRY_I(hipMalloc((void **)&d_gz, n + 64));   // the bit reader looks up to 16 bytes past a member
     HIP_TRY_I(hipMalloc((void **)&d_out, ix.text_bytes + 256));
     HIP_TRY_I(hipMalloc((void **)&d_ix, ix_bytes));
     uint64_t *d_in_off = (uint64_t *)d_ix, *d_out_off = d_in_off + nm;
