@@ -239,86 +239,108 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
         // The 64 lanes of the wave are at 64 different places of 64 different streams, and the wave pays for every
         // path any of its lanes takes: with "decode a symbol, then copy the whole match" an iteration cost the
         // longest copy loop among the lanes plus every special case some lane was in (about five memory round trips
-        // per symbol).  So a lane is in one of two states -- it decodes a symbol, or it has `clen` bytes of a match
-        // left to copy -- and an iteration of the wave is ONE decode for the lanes of the first kind followed by ONE
-        // copy step (one load round trip at most) for the lanes of the second.
+        // per symbol).  So an iteration of the wave has three phases, each at most once:
+        //   A  decode: a lane that has no match in progress decodes ONE symbol (LDS and registers only);
+        //   B  land:   the ONE load a lane issued in the previous iteration is waited for here -- behind the decode, the
+        //              round trip runs while the next symbol is decoded -- and stored (copy) or turned into `pat`;
+        //   C  act:    store the literal, or do one step of the match: issue the load for 8 bytes of a copy (stored in
+        //              the next B), store up to 64 bytes of a repeating pattern, ...
+        // Output is written in order: the store of B may run up to 7 bytes past its match (bytes of this member that
+        // later output overwrites), so nothing of C may be stored before it.
         const InfFast lcn = inf_fast(lc), dcn = inf_fast(dc);
         uint32_t clen = 0, cdist = 0;
-        uint64_t pat = 0;   // distances below 8: the bytes to repeat, replicated to 8 bytes
-        for (;;) {
+        uint64_t pat = 0;        // distances below 8: the bytes to repeat, replicated to 8 bytes
+        uint64_t pw = 0;         // the load in flight
+        uint32_t pend = 0;       // 0 none, 1 copy of 8 bytes to o + ppos, 2 the 8 bytes in front of a pattern match
+        uint32_t ppos = 0;
+        bool have_pat = false;
+        for (bool eob = false; !eob;) {
             if (budget-- == 0) { err = INF_EOUTPUT; break; }
-            if (clen == 0) {
+            int lit = -1;
+            if (clen == 0) {   // ---- A
                 b.refill();   // the one refill of the iteration: >= 56 bits
                 const int sym = inf_decode(b, lc, lcn);
                 if (sym < 0) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
                 if (sym < 256) {
                     if (pos >= olen) { err = INF_EOUTPUT; break; }
-                    o[pos++] = (uint8_t)sym;
-                    continue;
-                }
-                if (sym == 256) break;
-                const uint32_t ls = (uint32_t)sym - 257u;
-                if (ls >= 29u) { err = INF_ESYMBOL; break; }
-                // base and extra bits of a length / distance symbol by arithmetic (RFC 1951 section 3.2.5: after the
-                // first eight lengths / four distances the number of extra bits grows by one every four / two symbols)
-                // -- a lookup in a table in memory is a load the next step waits for, twice per match
-                uint32_t lext = 0, lbase = 3u + ls;
-                if (ls >= 8u) { lext = (ls - 4u) >> 2; lbase = 3u + ((4u + (ls & 3u)) << lext); }
-                if (ls == 28u) { lext = 0; lbase = 258u; }
-                const uint32_t len = lbase + b.get(lext);
-                const int ds = inf_decode(b, dc, dcn);
-                if (ds < 0 || ds >= INF_DCODES) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
-                uint32_t dext = 0, dbase = 1u + (uint32_t)ds;
-                if (ds >= 4) { dext = ((uint32_t)ds - 2u) >> 1; dbase = 1u + ((2u + ((uint32_t)ds & 1u)) << dext); }
-                const uint32_t dist = dbase + b.get(dext);
-                if (b.fail) { err = INF_ETRUNC; break; }
-                if (dist > pos || pos + len > olen) { err = INF_EOUTPUT; break; }
-                clen = len;
-                cdist = dist;
-                if (dist < 8u) {   // the last `dist` bytes of the output, replicated: byte j of pat = pattern[j mod dist]
-                    uint64_t w = 0;
-                    if (pos >= 8u) {
-                        __builtin_memcpy(&w, o + pos - 8u, 8);
-                        w >>= 8u * (8u - dist);
-                    } else {
-                        for (uint32_t i = 0; i < dist; ++i) w |= (uint64_t)o[pos - dist + i] << (8u * i);
-                    }
-                    for (uint32_t have = dist; have < 8u; have *= 2u) w |= w << (8u * have);
-                    pat = w;
+                    lit = sym;
+                } else if (sym == 256) {
+                    eob = true;
+                } else {
+                    const uint32_t ls = (uint32_t)sym - 257u;
+                    if (ls >= 29u) { err = INF_ESYMBOL; break; }
+                    // base and extra bits of a length / distance symbol by arithmetic (RFC 1951 section 3.2.5: after
+                    // the first eight lengths / four distances the number of extra bits grows by one every four / two
+                    // symbols) -- a lookup in a table in memory is a load the next step waits for, twice per match
+                    uint32_t lext = 0, lbase = 3u + ls;
+                    if (ls >= 8u) { lext = (ls - 4u) >> 2; lbase = 3u + ((4u + (ls & 3u)) << lext); }
+                    if (ls == 28u) { lext = 0; lbase = 258u; }
+                    const uint32_t len = lbase + b.get(lext);
+                    const int ds = inf_decode(b, dc, dcn);
+                    if (ds < 0 || ds >= INF_DCODES) { err = b.fail ? INF_ETRUNC : INF_ESYMBOL; break; }
+                    uint32_t dext = 0, dbase = 1u + (uint32_t)ds;
+                    if (ds >= 4) { dext = ((uint32_t)ds - 2u) >> 1; dbase = 1u + ((2u + ((uint32_t)ds & 1u)) << dext); }
+                    const uint32_t dist = dbase + b.get(dext);
+                    if (b.fail) { err = INF_ETRUNC; break; }
+                    if (dist > pos || pos + len > olen) { err = INF_EOUTPUT; break; }
+                    clen = len;
+                    cdist = dist;
+                    have_pat = false;
                 }
             }
-            // ---- one copy step.  A byte-wise `o[pos] = o[pos - dist]` makes every byte wait for the store before it;
-            // the steps are 8 bytes wide.  Wide stores may run up to 7 bytes past the match -- bytes of this member
-            // that later output overwrites -- so they are used while 8 bytes (64 for a pattern: 7 steps + 8) remain in the member.
-            if (cdist < 8u) {
-                const uint32_t step = (8u / cdist) * cdist;   // whole periods per store
-                if (pos + 64u <= olen) {                     // up to eight stores, no load: long runs in few iterations
+            // ---- B.  The wait is spelled out, for all lanes: with a load possibly in flight the compiler guards every
+            // later write of a register it shares with `pw` by a wait of its own -- between the pattern stores of C that
+            // was a memory round trip PER STORE.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            if (pend == 1u) {
+                __builtin_memcpy(o + ppos, &pw, 8);
+            } else if (pend == 2u) {   // byte j of pat = pattern[j mod dist], the pattern = the last `dist` bytes of the output
+                uint64_t w = pw >> (8u * (8u - cdist));
+                for (uint32_t have = cdist; have < 8u; have *= 2u) w |= w << (8u * have);
+                pat = w;
+                have_pat = true;
+            }
+            pend = 0;
+            // ---- C: what stores first, what issues the iteration's load last
+            const bool small = cdist < 8u;
+            uint32_t todo = 0;   // 1: load for a copy of 8 bytes, 2: load of the 8 bytes in front of a pattern match
+            if (lit >= 0) {
+                o[pos++] = (uint8_t)lit;
+            } else if (clen != 0) {
+                if (small && have_pat && pos + 64u <= olen) {   // up to eight stores, no load: long runs in few iterations
+                    const uint32_t step = (8u / cdist) * cdist;   // whole periods per store
                     const uint32_t n = min(clen, 8u * step);
 #pragma unroll
                     for (uint32_t j = 0; j < 8u; ++j)
                         if (j * step < n) __builtin_memcpy(o + pos + j * step, &pat, 8);
                     pos += n;
                     clen -= n;
-                } else {
+                } else if (small && !have_pat && pos >= 8u) {
+                    todo = 2u;
+                } else if (!small && cdist >= 32u && clen >= 32u) {   // source and destination of a 32-byte step cannot overlap
+                    uint64_t w[4];
+                    __builtin_memcpy(w, o + pos - cdist, 32);
+                    __builtin_memcpy(o + pos, w, 32);
+                    pos += 32u;
+                    clen -= 32u;
+                } else if (!small && pos + 8u <= olen) {
+                    todo = 1u;
+                } else {   // the first or last bytes of the member
                     for (; clen; --clen, ++pos) o[pos] = o[pos - cdist];
                 }
-            } else if (cdist >= 32u && clen >= 32u) {   // source and destination of a 32-byte step cannot overlap
-                uint64_t w[4];
-                __builtin_memcpy(w, o + pos - cdist, 32);
-                __builtin_memcpy(o + pos, w, 32);
-                pos += 32u;
-                clen -= 32u;
-            } else if (pos + 8u <= olen) {
-                uint64_t w;
-                __builtin_memcpy(&w, o + pos - cdist, 8);
-                __builtin_memcpy(o + pos, &w, 8);
-                const uint32_t n = min(clen, 8u);
-                pos += n;
-                clen -= n;
-            } else {
-                for (; clen; --clen, ++pos) o[pos] = o[pos - cdist];
+            }
+            if (todo) {   // ONE load instruction for both kinds (two would wait for each other: same destination register)
+                __builtin_memcpy(&pw, o + pos - (todo == 1u ? cdist : 8u), 8);
+                pend = todo;
+                if (todo == 1u) {
+                    ppos = pos;
+                    const uint32_t n = min(clen, 8u);
+                    pos += n;
+                    clen -= n;
+                }
             }
         }
+        if (pend == 1u) __builtin_memcpy(o + ppos, &pw, 8);   // (left by a break)
     }
     if (err == INF_OK && pos != olen) err = INF_ESIZE;
     if (err == INF_OK) {
