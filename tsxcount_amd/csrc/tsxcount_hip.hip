@@ -1059,6 +1059,9 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         if (fuse == 2) {
             // two kernels: strip descriptions (16 B per strip with a k-mer start, one region per wave, in buffer 0 --
             // level 2 overwrites it later), then the walk with every lane busy
+            // all keys stay on this GPU: a ring flush per quarter strip (TSX_HIP_WALK_FLUSHQ=2|4: experiments)
+            uint32_t local_fq = 1u;
+            if (const char *e = getenv("TSX_HIP_WALK_FLUSHQ")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) local_fq = (uint32_t)v; }
             // (TSX_HIP_LOCAL_LONG=1: four strips per 32-byte description, as in the exchange of a sharded run)
             const char *ll_env = getenv("TSX_HIP_LOCAL_LONG");
             const int lng = ll_env ? (atoi(ll_env) != 0) : 0;
@@ -1071,7 +1074,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             hipLaunchKernelGGL(walk_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
                                (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                                (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, lng, 1u);
+                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, lng, local_fq);
         } else {
             hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
