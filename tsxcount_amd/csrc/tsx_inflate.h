@@ -9,6 +9,11 @@
 // (RFC 1951: stored, fixed and dynamic Huffman blocks), 64 members per workgroup, the decode tables of a lane
 // in LDS (interleaved by lane: conflict-free), the output written straight into the text buffer in HBM that
 // the scan kernels read.  The CRC-32 of every member is checked on the device as well.
+// What shapes the kernel: the 64 lanes of a wave are in 64 unrelated streams, a wave pays for every path any of
+// its lanes takes, and s_waitcnt counts per wave -- so the symbol loop is three phases that every lane passes
+// once per iteration (decode one symbol without branches on its bits / land the one load in flight / store or
+// issue the next load), see inflate_members_kernel.  The kernel's time is the latency chain of one lane through
+// its member (about 20 ms for 64 KiB), whatever the number of members.
 // A `.gz` file that is not BGZF is not handled here (tsx_hip_bgzf_index_host says so); the CLI then falls
 // back to zlib on the host.
 #pragma once
