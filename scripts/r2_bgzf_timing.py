@@ -11,7 +11,8 @@ buf = torch.empty(nb + 256, dtype=torch.uint8, device="cuda:0")
 torch.cuda.synchronize()
 T.synth_fastq_device(seed, 0, reads, k, buf.data_ptr(), nb)
 text = bytes(buf[:nb].cpu().numpy())
-t0 = time.perf_counter(); z = T.bgzf_compress(text, level=1); t1 = time.perf_counter()
+level = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+t0 = time.perf_counter(); z = T.bgzf_compress(text, level=level); t1 = time.perf_counter()
 print("text %d bytes, BGZF %d bytes (%.2fx), %d members; compress %.1f s" % (nb, len(z), nb / len(z), T.bgzf_index(z)[0], t1 - t0))
 t0 = time.perf_counter(); back = gzip.decompress(z); t1 = time.perf_counter()
 assert back == text
