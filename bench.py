@@ -143,6 +143,39 @@ def run_check(args, m, T, TD, dist, torch, dist_on, sharded, world, rank, red, d
     return ok, detail
 
 
+def self_launch(n):
+    """Start n ranks of this script through torch.distributed.run as a child process; returns its exit code.
+    Nothing here imports torch or touches the GPU."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    lines = []
+    for raw in child.stdout:               # rank 0 prints ONE JSON line; anything else on stdout goes to stderr
+        line = raw.decode("utf-8", "replace")
+        if line.lstrip().startswith("{") and '"metric"' in line:
+            lines.append(line)
+        else:
+            sys.stderr.write(line)
+    rc = child.wait()
+    for line in lines[-1:]:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: the ranks exited 0 without a result line\n")
+        return 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,12 +199,16 @@ def main():
                          "the only way to push the RCCL leg through its API on a 1-GPU box")
     args = ap.parse_args()
 
-    # One process per GPU: the launcher (python -m torch.distributed.run) sets WORLD_SIZE.  A bare
-    # `python bench.py --gpus 8` would silently measure one GPU, so it is refused -- before torch
-    # or the GPU is touched.
+    # One process per GPU.  Under a launcher (python -m torch.distributed.run sets WORLD_SIZE) this process is one
+    # rank.  A bare `python bench.py --gpus N` with N > 1 starts the N ranks itself -- as CHILD processes, before
+    # torch or the GPU is touched here (no exec from a process that has initialised the GPU) -- relays rank 0's
+    # JSON line and exits with the children's code: one command runs the job, like the reference's CLI
+    # (src/mains/main.cpp:404-507).  A mismatch inside a launcher is refused.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != env_world:
-        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d. Launch one rank per GPU:\n"
+        sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d. Launch one rank per GPU:\n"
                          "  python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
                          "--master-port 29671 bench.py --gpus %d --steps %d --warmup %d\n"
                          % (args.gpus, env_world, args.gpus, args.gpus, args.steps, args.warmup))
@@ -339,6 +376,7 @@ def main():
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
+            "rccl_ranks": (dist.get_world_size() if dist_on else 0), "backend": (dist.get_backend() if dist_on else None),
             "config": {"workload": "synthetic FASTQ (generateFakeSequences.py shape), %d reads/GPU = %d k-mers/GPU, "
                                    "k=%d, table 2^%d slots/GPU, %s insert path%s"
                                    % (args.reads, kmers_rank, args.k, args.l,

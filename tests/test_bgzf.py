@@ -77,6 +77,29 @@ def test_count_fastq_from_bgzf_equals_plain_text():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,block", [(31, 65280), (127, 4000), (21, 700)])
+def test_bgzf_is_inflated_and_counted_in_batches(monkeypatch, k, block):
+    """A large .fastq.gz is inflated a batch of members at a time into two text buffers (1 GiB of text per batch by
+    default; the smallest batch, 128 KiB, here): lines, records and k-mers run across the batch seams, members of 4000
+    and 700 bytes put dozens to hundreds of members into a batch.  Counts must equal those of the plain text, and the
+    host copy of the inflated text zlib's."""
+    import tsxcount_amd as T
+    from tsxcount_amd import synth
+    text = synth.fastq(23, 0, 700)           # 1.2 MB: ten batches
+    z = T.bgzf_compress(text, level=1, block=block)
+    monkeypatch.setenv("TSX_HIP_BGZF_BATCH", "1")      # clamped to the minimum
+    assert T.bgzf_inflate(z) == text
+    a, b = T.TSXHashMapHIP(21, 0, k), T.TSXHashMapHIP(21, 0, k)
+    a.countFastq(text)
+    b.countFastqBgzf(z)
+    sa, sb = a.stats(), b.stats()
+    assert sa["kmers_added"] == sb["kmers_added"] > 0 and sa["distinct"] == sb["distinct"]
+    ka, ca = a.getAllKmers()
+    assert np.array_equal(b.getKmerCounts(ka), ca)
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
 def test_damaged_members_are_refused():
     import tsxcount_amd as T
     from tsxcount_amd import synth

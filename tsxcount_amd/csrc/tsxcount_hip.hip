@@ -104,6 +104,13 @@ struct tsx_hip_map {
     size_t sh_cnt_entries = 0;
     std::deque<long> ev_open;        // tuples of shard scans whose partition phase has not run yet (oldest first)
     size_t ev_used = 0;
+    // Ordering between the map's own stream and a caller's stream (the `stream` argument of the *_device entry
+    // points): tsx_hip_clear works on the map's stream and records clear_ev behind it; every entry point that
+    // launches on a caller's stream waits for that event first.  The other way round, the last caller's stream
+    // is remembered (`foreign`) and tsx_hip_clear / tsx_hip_sync order themselves behind what was queued there.
+    hipEvent_t clear_ev = nullptr, join_ev = nullptr;
+    bool clear_ev_set = false;
+    hipStream_t foreign = nullptr;
 };
 
 static const size_t STAGE_PAD = 256;
@@ -112,6 +119,7 @@ static const int EV_N = 8;   // timing events per piece: before pass 1, before t
 static bool can_partition(const tsx_hip_map *m);
 static int clear_impl(tsx_hip_map *m, bool full);
 static int ensure_zeroed(tsx_hip_map *m, hipStream_t st);
+static inline void join_foreign(tsx_hip_map *m, bool host_wait);
 
 extern "C" int tsx_hip_key_limbs(int k) { return (k < 1 || k > 127) ? TSX_HIP_EINVAL : (2 * k + 63) / 64; }
 
@@ -473,6 +481,8 @@ extern "C" int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storage
     HIP_TRY_C(hipGetDeviceProperties(&prop, device));
     m->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY_C(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreateWithFlags(&m->clear_ev, hipEventDisableTiming));
+    HIP_TRY_C(hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming));
     TableParams &p = m->p;
     HIP_TRY_C(hipMalloc((void **)&p.table, m->lay.table_bytes));
     HIP_TRY_C(hipMalloc((void **)&p.sec_keys, (p.sec_mask + 1) * 8));
@@ -538,6 +548,8 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     }
     if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+    if (m->clear_ev) (void)hipEventDestroy(m->clear_ev);
+    if (m->join_ev) (void)hipEventDestroy(m->join_ev);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -563,6 +575,7 @@ __global__ __launch_bounds__(NT) void sec_clear_kernel(TableParams p, int force)
 // or zeroed when it has no keys -- and every other entry point zeroes the table first (ensure_zeroed).
 static int clear_impl(tsx_hip_map *m, bool full) {
     HIP_TRY(hipSetDevice(m->device));
+    join_foreign(m, false);
     if (full || !can_partition(m)) {
         HIP_TRY(hipMemsetAsync(m->p.table, 0, m->lay.table_bytes, m->stream));
         m->fresh = false;
@@ -573,6 +586,8 @@ static int clear_impl(tsx_hip_map *m, bool full) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(m->p.stats, 0, ST_N * sizeof(unsigned long long), m->stream));
     HIP_TRY(hipMemsetAsync(m->p.seg_dirty, 0, (size_t)(m->lay.slots >> m->p.S), m->stream));
+    HIP_TRY(hipEventRecord(m->clear_ev, m->stream));
+    m->clear_ev_set = true;
     return TSX_HIP_OK;
 }
 
@@ -598,6 +613,7 @@ static int read_stats(tsx_hip_map *m, unsigned long long *st) {
 extern "C" int tsx_hip_sync(tsx_hip_map *m) {
     if (!m) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
+    join_foreign(m, true);
     unsigned long long st[ST_N];
     int rc = read_stats(m, st);
     if (rc != TSX_HIP_OK) return rc;
@@ -607,7 +623,24 @@ extern "C" int tsx_hip_sync(tsx_hip_map *m) {
     return TSX_HIP_OK;
 }
 
-static inline hipStream_t pick_stream(tsx_hip_map *m, void *stream) { return stream ? (hipStream_t)stream : m->stream; }
+static inline hipStream_t pick_stream(tsx_hip_map *m, void *stream) {
+    hipStream_t st = stream ? (hipStream_t)stream : m->stream;
+    if (st != m->stream) {
+        if (m->clear_ev_set) (void)hipStreamWaitEvent(st, m->clear_ev, 0);   // behind the last tsx_hip_clear
+        m->foreign = st;
+    }
+    return st;
+}
+// The map's own stream is about to touch what a caller's stream may still be working on: order it behind.
+static inline void join_foreign(tsx_hip_map *m, bool host_wait) {
+    if (!m->foreign) return;
+    if (host_wait) {
+        (void)hipStreamSynchronize(m->foreign);
+        m->foreign = nullptr;
+    } else if (m->join_ev && hipEventRecord(m->join_ev, m->foreign) == hipSuccess) {
+        (void)hipStreamWaitEvent(m->stream, m->join_ev, 0);
+    }
+}
 static inline int grid_for(const tsx_hip_map *m, uint64_t work_items, int per_cu) {
     uint64_t blocks = (work_items + NT - 1) / NT;
     uint64_t cap = (uint64_t)m->cus * per_cu;
@@ -1707,12 +1740,34 @@ extern "C" int tsx_hip_bgzf_index_host(const void *gz, size_t n, size_t *members
     return TSX_HIP_OK;
 }
 
-// gz (host) -> inflated text in *d_text (device, 16-byte aligned, text_bytes + 256 bytes; the caller frees it)
-static int inflate_bgzf_to_device(const uint8_t *gz, size_t n, hipStream_t st, uint8_t **d_text, size_t *text_bytes) {
-    BgzfIndex ix;
-    if (!bgzf_index(gz, n, ix)) { g_last_error = "not a BGZF file (no BC extra field in every gzip member)"; return TSX_HIP_EINVAL; }
-    const size_t nm = ix.in_off.size();
-    uint8_t *d_gz = nullptr, *d_out = nullptr, *d_ix = nullptr;
+// Device scratch of the BGZF path: the compressed bytes and the member index of ONE batch of members.
+struct BgzfDev {
+    uint8_t *d_gz = nullptr, *d_ix = nullptr;
+    size_t gz_cap = 0, ix_cap = 0;
+    uint32_t *d_tab = nullptr;      // CRC-32 tables
+    ~BgzfDev() { (void)hipFree(d_gz); (void)hipFree(d_ix); (void)hipFree(d_tab); }
+};
+
+// Members are inflated in BATCHES of at most this many bytes of text (whole members, at least one), so that a large
+// .fastq.gz needs two batch-sized text buffers instead of the whole text at once.  TSX_HIP_BGZF_BATCH: tests.
+static size_t bgzf_batch_bytes() {
+    size_t v = (size_t)1 << 30;
+    if (const char *e = getenv("TSX_HIP_BGZF_BATCH")) { const long long x = atoll(e); if (x > 0) v = (size_t)x; }
+    return std::max<size_t>(v, (size_t)128 << 10);
+}
+// [m0, m1): the next batch from member m0 on -- members while the text stays within `batch` (or below 4 KiB)
+static size_t bgzf_next_batch(const BgzfIndex &ix, size_t m0, size_t batch) {
+    size_t m1 = m0, acc = 0;
+    while (m1 < ix.in_off.size() && (m1 == m0 || acc < 4096 || acc + ix.out_len[m1] <= batch)) acc += ix.out_len[m1++];
+    return m1;
+}
+
+// Inflates members [m0, m1) of gz: the text of member m0 starts at d_out[0].  Waits for the kernel and checks
+// every member's status (stored / fixed / dynamic blocks decoded, ISIZE and CRC-32 right).
+static int inflate_batch(const uint8_t *gz, size_t n, const BgzfIndex &ix, size_t m0, size_t m1, BgzfDev &dv,
+                         uint8_t *d_out, hipStream_t st) {
+    const size_t nm = m1 - m0;
+    if (nm == 0) return TSX_HIP_OK;
     // CRC-32 tables for eight bytes per step: crc_tab[j][v] = CRC of byte v followed by j zero bytes
     static uint32_t crc_tab[8 * 256];
     static std::once_flag crc_once;
@@ -1726,87 +1781,128 @@ static int inflate_bgzf_to_device(const uint8_t *gz, size_t n, hipStream_t st, u
             for (uint32_t i = 0; i < 256; ++i)
                 crc_tab[j * 256 + i] = (crc_tab[(j - 1) * 256 + i] >> 8) ^ crc_tab[crc_tab[(j - 1) * 256 + i] & 0xFFu];
     });
-    // one allocation for the index: in_off | out_off | in_len | out_len | crc | status | crc tables
-    const size_t ix_bytes = nm * (8 + 8 + 4 + 4 + 4 + 4) + sizeof(crc_tab);
-    auto cleanup = [&]() { (void)hipFree(d_gz); (void)hipFree(d_ix); };
-#define HIP_TRY_I(expr)                                                                             \
-    do {                                                                                            \
-        hipError_t _e = (expr);                                                                     \
-        if (_e != hipSuccess) {                                                                     \
-            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
-            cleanup(); (void)hipFree(d_out);                                                        \
-            return (_e == hipErrorOutOfMemory) ? TSX_HIP_ENOMEM : TSX_HIP_EHIP;                     \
-        }                                                                                           \
-    } while (0)
-    HIP_TRY_I(hipMalloc((void **)&d_gz, n + 64));   // the bit reader looks up to 16 bytes past a member
-    HIP_TRY_I(hipMalloc((void **)&d_out, ix.text_bytes + 256));
-    HIP_TRY_I(hipMalloc((void **)&d_ix, ix_bytes));
-    uint64_t *d_in_off = (uint64_t *)d_ix, *d_out_off = d_in_off + nm;
-    uint32_t *d_in_len = (uint32_t *)(d_out_off + nm), *d_out_len = d_in_len + nm, *d_crc = d_out_len + nm,
-             *d_status = d_crc + nm, *d_tab = d_status + nm;
-    HIP_TRY_I(hipMemcpyAsync(d_gz, gz, n, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_in_off, ix.in_off.data(), nm * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_out_off, ix.out_off.data(), nm * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_in_len, ix.in_len.data(), nm * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_out_len, ix.out_len.data(), nm * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_crc, ix.crc.data(), nm * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemcpyAsync(d_tab, crc_tab, sizeof(crc_tab), hipMemcpyHostToDevice, st));
-    HIP_TRY_I(hipMemsetAsync(d_status, 0xFF, nm * 4, st));
-    HIP_TRY_I(hipMemsetAsync(d_out + ix.text_bytes, '\n', 256, st));
-    HIP_TRY_I(hipFuncSetAttribute((const void *)inflate_members_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)INF_LDS_BYTES));
+    if (!dv.d_tab) {
+        HIP_TRY(hipMalloc((void **)&dv.d_tab, sizeof(crc_tab)));
+        HIP_TRY(hipMemcpyAsync(dv.d_tab, crc_tab, sizeof(crc_tab), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipFuncSetAttribute((const void *)inflate_members_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)INF_LDS_BYTES));
+    }
+    const size_t lo = (size_t)ix.in_off[m0], hi = (size_t)ix.in_off[m1 - 1] + ix.in_len[m1 - 1];
+    const size_t gz_bytes = std::min(n, hi + 16) - lo;       // the bit reader looks up to 16 bytes past a member
+    int rc = grow(st, dv.d_gz, dv.gz_cap, (hi - lo) + 64);
+    if (rc != TSX_HIP_OK) return rc;
+    // one allocation for the index: in_off | out_off | in_len | out_len | crc | status
+    rc = grow(st, dv.d_ix, dv.ix_cap, nm * (8 + 8 + 4 + 4 + 4 + 4));
+    if (rc != TSX_HIP_OK) return rc;
+    std::vector<uint64_t> in_off(nm), out_off(nm);
+    for (size_t i = 0; i < nm; ++i) { in_off[i] = ix.in_off[m0 + i] - lo; out_off[i] = ix.out_off[m0 + i] - ix.out_off[m0]; }
+    uint64_t *d_in_off = (uint64_t *)dv.d_ix, *d_out_off = d_in_off + nm;
+    uint32_t *d_in_len = (uint32_t *)(d_out_off + nm), *d_out_len = d_in_len + nm, *d_crc = d_out_len + nm, *d_status = d_crc + nm;
+    HIP_TRY(hipMemcpyAsync(dv.d_gz, gz + lo, gz_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_in_off, in_off.data(), nm * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_out_off, out_off.data(), nm * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_in_len, ix.in_len.data() + m0, nm * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_out_len, ix.out_len.data() + m0, nm * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_crc, ix.crc.data() + m0, nm * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_status, 0xFF, nm * 4, st));
     hipLaunchKernelGGL(inflate_members_kernel, dim3((uint32_t)((nm + INF_NT - 1) / INF_NT)), dim3(INF_NT), INF_LDS_BYTES, st,
-                       (const uint8_t *)d_gz, (const uint64_t *)d_in_off, (const uint32_t *)d_in_len,
+                       (const uint8_t *)dv.d_gz, (const uint64_t *)d_in_off, (const uint32_t *)d_in_len,
                        (const uint64_t *)d_out_off, (const uint32_t *)d_out_len, (const uint32_t *)d_crc, (uint32_t)nm, d_out,
-                       d_status, (const uint32_t *)d_tab);
-    HIP_TRY_I(hipGetLastError());
+                       d_status, (const uint32_t *)dv.d_tab);
+    HIP_TRY(hipGetLastError());
     std::vector<uint32_t> status(nm);
-    HIP_TRY_I(hipMemcpyAsync(status.data(), d_status, nm * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY_I(hipStreamSynchronize(st));
-#undef HIP_TRY_I
-    cleanup();
+    HIP_TRY(hipMemcpyAsync(status.data(), d_status, nm * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));      // (also: in_off / out_off of this frame have been copied)
     for (size_t i = 0; i < nm; ++i)
         if (status[i] != INF_OK) {
             static const char *why[] = {"ok", "deflate data truncated", "reserved block type", "stored block length check",
                                         "bad code lengths", "invalid symbol", "output overrun or distance too far",
                                         "size differs from ISIZE", "CRC-32 mismatch"};
-            g_last_error = "BGZF member " + std::to_string(i) + ": " + (status[i] < 9 ? why[status[i]] : "not decoded");
-            (void)hipFree(d_out);
+            g_last_error = "BGZF member " + std::to_string(m0 + i) + ": " + (status[i] < 9 ? why[status[i]] : "not decoded");
             return TSX_HIP_EINVAL;
         }
-    *d_text = d_out;
-    *text_bytes = (size_t)ix.text_bytes;
     return TSX_HIP_OK;
+}
+
+static inline size_t bgzf_batch_text(const BgzfIndex &ix, size_t m0, size_t m1) {
+    return (size_t)((m1 < ix.out_off.size() ? ix.out_off[m1] : ix.text_bytes) - ix.out_off[m0]);
 }
 
 extern "C" int tsx_hip_inflate_bgzf_host(int device, const void *gz, size_t n, void *out_host, size_t out_cap,
                                          size_t *out_bytes) {
     if ((!gz && n) || !out_bytes) return TSX_HIP_EINVAL;
+    BgzfIndex ix;
+    if (!bgzf_index((const uint8_t *)gz, n, ix)) { g_last_error = "not a BGZF file (no BC extra field in every gzip member)"; return TSX_HIP_EINVAL; }
+    *out_bytes = (size_t)ix.text_bytes;
+    if (ix.text_bytes > out_cap || (ix.text_bytes && !out_host)) return TSX_HIP_ERANGE;
     HIP_TRY(hipSetDevice(device));
-    uint8_t *d_text = nullptr;
-    size_t nb = 0;
-    int rc = inflate_bgzf_to_device((const uint8_t *)gz, n, nullptr, &d_text, &nb);
-    if (rc != TSX_HIP_OK) return rc;
-    *out_bytes = nb;
-    if (nb > out_cap || (nb && !out_host)) { (void)hipFree(d_text); return TSX_HIP_ERANGE; }
-    hipError_t e = nb ? hipMemcpy(out_host, d_text, nb, hipMemcpyDeviceToHost) : hipSuccess;
-    (void)hipFree(d_text);
-    if (e != hipSuccess) { g_last_error = hipGetErrorString(e); return TSX_HIP_EHIP; }
-    return TSX_HIP_OK;
+    BgzfDev dv;
+    uint8_t *d_out = nullptr;
+    size_t out_have = 0;
+    const size_t batch = bgzf_batch_bytes();
+    int rc = TSX_HIP_OK;
+    for (size_t m0 = 0; m0 < ix.in_off.size() && rc == TSX_HIP_OK;) {
+        const size_t m1 = bgzf_next_batch(ix, m0, batch), nb = bgzf_batch_text(ix, m0, m1);
+        rc = grow((hipStream_t) nullptr, d_out, out_have, nb + 256);
+        if (rc == TSX_HIP_OK) rc = inflate_batch((const uint8_t *)gz, n, ix, m0, m1, dv, d_out, nullptr);
+        if (rc == TSX_HIP_OK && nb && hipMemcpy((uint8_t *)out_host + ix.out_off[m0], d_out, nb, hipMemcpyDeviceToHost) != hipSuccess) {
+            g_last_error = "hipMemcpy of the inflated text failed";
+            rc = TSX_HIP_EHIP;
+        }
+        m0 = m1;
+    }
+    (void)hipFree(d_out);
+    return rc;
 }
+
+// The text never exists as a whole: batch b is inflated into one of two buffers BEHIND the last BGZF_PRE + 16 bytes
+// of batch b-1, and counted as a piece that owns the start positions up to BGZF_PRE bytes before its end (the last
+// batch: all of them) -- the k-1 bytes a window needs behind its start are always there, the byte in front of a
+// piece (is its first line open?) as well.  On an inflate error the table holds the batches before it.
+static const size_t BGZF_PRE = 256;   // >= k - 1, a multiple of 16
 
 extern "C" int tsx_hip_count_fastq_bgzf_host(tsx_hip_map *m, const void *gz, size_t n) {
     if (!m || (!gz && n)) return TSX_HIP_EINVAL;
     if (m->p.lg != m->p.l) return TSX_HIP_EINVAL;   // see tsx_hip_count_fastq_device
+    BgzfIndex ix;
+    if (!bgzf_index((const uint8_t *)gz, n, ix)) { g_last_error = "not a BGZF file (no BC extra field in every gzip member)"; return TSX_HIP_EINVAL; }
     HIP_TRY(hipSetDevice(m->device));
-    hipStream_t st = pick_stream(m, nullptr);
-    uint8_t *d_text = nullptr;
-    size_t nb = 0;
-    int rc = inflate_bgzf_to_device((const uint8_t *)gz, n, st, &d_text, &nb);
-    if (rc != TSX_HIP_OK) return rc;
-    rc = tsx_hip_count_fastq_device(m, d_text, nb, nullptr);
+    hipStream_t st = m->stream;
+    join_foreign(m, false);
+    HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    const size_t batch = bgzf_batch_bytes(), nm = ix.in_off.size(), head = BGZF_PRE + 16;
+    size_t biggest = 0;
+    for (size_t m0 = 0; m0 < nm;) { const size_t m1 = bgzf_next_batch(ix, m0, batch); biggest = std::max(biggest, bgzf_batch_text(ix, m0, m1)); m0 = m1; }
+    BgzfDev dv;
+    uint8_t *d_txt[2] = {nullptr, nullptr};
+    const size_t buf_bytes = head + biggest + 256;
+    int rc = TSX_HIP_OK;
+    for (int i = 0; i < 2 && rc == TSX_HIP_OK; ++i)
+        if ((i == 0 || bgzf_next_batch(ix, 0, batch) < nm) && hipMalloc((void **)&d_txt[i], buf_bytes) != hipSuccess) {
+            g_last_error = "hipMalloc of a BGZF text buffer failed";
+            rc = TSX_HIP_ENOMEM;
+        }
+    size_t prev_len = 0;   // bytes of text in the previous batch's buffer, behind its head
+    int b = 0;
+    for (size_t m0 = 0; m0 < nm && rc == TSX_HIP_OK; b ^= 1) {
+        const size_t m1 = bgzf_next_batch(ix, m0, batch), nb = bgzf_batch_text(ix, m0, m1);
+        const bool first = (m0 == 0), last = (m1 == nm);
+        uint8_t *buf = d_txt[b];
+        if (!first)   // the end of the text so far (it may reach back into the previous buffer's own head)
+            if (hipMemcpyAsync(buf, d_txt[b ^ 1] + prev_len, head, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        rc = inflate_batch((const uint8_t *)gz, n, ix, m0, m1, dv, buf + head, st);
+        if (rc != TSX_HIP_OK) break;
+        if (hipMemsetAsync(buf + head + nb, '\n', 256, st) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        // piece: from `from` (16-byte aligned) to the end of this batch's text; it owns all start positions but the
+        // last BGZF_PRE (they belong to the next piece, which sees them again behind its own head)
+        const size_t from = first ? head : 16, len = head + nb - from;
+        const size_t own = last ? len : (len > BGZF_PRE ? len - BGZF_PRE : 0);
+        rc = run_fastq_piece(m, buf + from, len, own, first ? 0 : -1, st);
+        prev_len = nb;
+        m0 = m1;
+    }
     hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(d_text);
+    (void)hipFree(d_txt[0]); (void)hipFree(d_txt[1]);
     if (rc == TSX_HIP_OK && e != hipSuccess) { g_last_error = hipGetErrorString(e); rc = TSX_HIP_EHIP; }
     return rc;
 }
@@ -1947,6 +2043,7 @@ static int lookup_host(tsx_hip_map *m, const uint64_t *kmers, size_t n, uint64_t
     if (!m || ((!kmers || !counts_out) && n)) return TSX_HIP_EINVAL;
     if (n == 0) return TSX_HIP_OK;
     HIP_TRY(hipSetDevice(m->device));
+    join_foreign(m, false);
     int rcz = ensure_zeroed(m, m->stream);
     if (rcz != TSX_HIP_OK) return rcz;
     const size_t wk = (size_t)m->p.wk, kb = n * wk * 8;
@@ -1985,6 +2082,7 @@ extern "C" int tsx_hip_kmer_starts_host(tsx_hip_map *m, uint8_t *bits_out, size_
     if (!m || !bits_out || nbytes * 8 < m->lay.slots) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
     const uint64_t nb = (m->lay.slots + 7) / 8;
+    join_foreign(m, false);
     int rcz = ensure_zeroed(m, m->stream);
     if (rcz != TSX_HIP_OK) return rcz;
     uint8_t *d = nullptr;
@@ -2017,6 +2115,7 @@ extern "C" int tsx_hip_debug_counters(tsx_hip_map *m, uint64_t *out8) {
 extern "C" int tsx_hip_get_stats(tsx_hip_map *m, tsx_hip_stats *out) {
     if (!m || !out) return TSX_HIP_EINVAL;
     HIP_TRY(hipSetDevice(m->device));
+    join_foreign(m, false);
     int rcz = ensure_zeroed(m, m->stream);
     if (rcz != TSX_HIP_OK) return rcz;
     HIP_TRY(hipMemsetAsync(m->p.stats + ST_SCRATCH, 0, 2 * sizeof(unsigned long long), m->stream));

@@ -226,21 +226,50 @@ class ShardedCounter:
     MIN_WINDOW = 32 << 20      # bytes of text below which a step is not split further
 
     def __init__(self, hmap, max_text_bytes, group=None, windows=None):
-        from . import _check
         self.m = hmap
         self.comm = _comm(group)
         self.world, self.rank = self.comm.world, self.comm.rank
         assert self.world == 1 << hmap.layout.shard_bits, "world size must equal 2^shard_bits"
         self.dev = torch.device("cuda", hmap.device)
+        # Every rank must run the SAME number of windows (each window is a round of collectives) over the same
+        # window length, whatever its own text size: both are derived from the largest text of any rank.
+        if self.world > 1:
+            t = torch.tensor([int(max_text_bytes)], dtype=torch.int64, device="cpu" if self.comm.gloo else self.dev)
+            self.comm.all_reduce(t, "max")
+            max_text_bytes = int(t.item())
+        self.max_text_bytes = int(max_text_bytes)
         if windows is None:
             windows = int(os.environ.get("TSX_HIP_SHARD_WINDOWS", "0")) or max(1, min(4, max_text_bytes // self.MIN_WINDOW))
         self.windows = max(1, int(windows))
-
         self.win_bytes = max(4096, ((max_text_bytes + self.windows - 1) // self.windows + 4095) & ~4095)
-        cap = ctypes.c_size_t(0)
-        _check(hmap._lib.tsx_hip_shard_send_capacity(hmap.handle, self.win_bytes + 256, ctypes.byref(cap)))
-        self.send_cap = cap.value
         i64 = dict(dtype=torch.int64, device=self.dev)
+        self.send_cap = 0                         # key-exchange buffers: allocated by the first keys-mode step
+        self.sums = torch.zeros((2,), **i64)      # [0] += keys written by the scans, [1] += keys read by the build
+        self.cs = torch.cuda.Stream(self.dev)     # every kernel of a step
+        self.xs = torch.cuda.Stream(self.dev)     # the collectives
+        self.ev_scan = [torch.cuda.Event() for _ in range(2)]
+        self.ev_exch = [torch.cuda.Event() for _ in range(2)]
+        self.last = {}
+
+    def _window(self, i, nbytes):
+        """(offset, length) of window i of a text of nbytes: windows past the end of a short (or empty) text are
+        empty, their offset the end of the text rounded down to the 16 bytes the entry points ask for."""
+        off = i * self.win_bytes
+        if off >= nbytes:
+            return nbytes & ~15, 0
+        return off, min(self.win_bytes, nbytes - off)
+
+    def _ensure_key_buffers(self):
+        """Send / receive / hot-list buffers of the key exchange, sized by the map's CURRENT record format (a FASTA
+        text holds up to twice the k-mers per byte): allocated on the first keys-mode step, again when the
+        capacity the library asks for has grown."""
+        from . import _check
+        cap = ctypes.c_size_t(0)
+        _check(self.m._lib.tsx_hip_shard_send_capacity(self.m.handle, self.win_bytes + 256, ctypes.byref(cap)))
+        if cap.value <= self.send_cap:
+            return
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        self.send_cap = cap.value
         self.send = [torch.empty((self.send_cap,), **i64) for _ in range(2)]
         # receive buffer: one part per window -- own keys in front (any number up to the window's total),
         # the peers' behind them
@@ -252,20 +281,13 @@ class ShardedCounter:
         self.hot_n = [torch.zeros((1,), **i64) for _ in range(2)]
         self.hot_all_k = [torch.zeros((0,), **i64) for _ in range(self.windows)]
         self.hot_all_c = [torch.zeros((0,), **i64) for _ in range(self.windows)]
-        self.sums = torch.zeros((2,), **i64)      # [0] += keys written by the scans, [1] += keys read by the build
-        self.cs = torch.cuda.Stream(self.dev)     # every kernel of a step
-        self.xs = torch.cuda.Stream(self.dev)     # the collectives
-        self.ev_scan = [torch.cuda.Event() for _ in range(2)]
-        self.ev_exch = [torch.cuda.Event() for _ in range(2)]
-        self.last = {}
 
     def _scan(self, i, text_ptr, nbytes):
         m, L, vp, b = self.m, self.m._lib, ctypes.c_void_p, i & 1
-        off = i * self.win_bytes
-        ln = max(0, min(self.win_bytes, nbytes - off))
+        off, ln = self._window(i, nbytes)
         own_ptr = self.recv.data_ptr() + i * self.part * 8
         rc = L.tsx_hip_shard_scan_window_device(
-            m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln, vp(self.send[b].data_ptr()), self.send_cap,
+            m.handle, vp(text_ptr), nbytes, off, ln, vp(self.send[b].data_ptr()), self.send_cap,
             vp(own_ptr), self.part, vp(self.counts[b].data_ptr()),
             vp(self.hot_k[b].data_ptr()), vp(self.hot_c[b].data_ptr()), self.HOT_CAP, vp(self.hot_n[b].data_ptr()),
             vp(self.sums.data_ptr()), vp(self.cs.cuda_stream))
@@ -296,7 +318,9 @@ class ShardedCounter:
         from . import OK, TSXException, _check
         m, L, vp = self.m, self.m._lib, ctypes.c_void_p
         world, comm = self.world, self.comm
-        nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
+        if nbytes > self.max_text_bytes:
+            raise ValueError("sharded step: text of %d bytes, the counter was made for %d" % (nbytes, self.max_text_bytes))
+        nwin = self.windows      # the same on every rank: a window is a round of collectives (short texts: empty windows)
         nslots = nwin            # one walk launch (= one set of level-1 lists) per window, over the descriptions of ALL GPUs
         i64 = dict(dtype=torch.int64, device=self.dev)
         # long descriptions (four strips in 32 bytes: half the bytes per start position) unless TSX_HIP_SHARD_LONG=0
@@ -317,9 +341,8 @@ class ShardedCounter:
 
         def desc(i):
             b = i & 1
-            off = i * self.win_bytes
-            ln = max(0, min(self.win_bytes, nbytes - off))
-            rc = L.tsx_hip_shard_desc_window_device(m.handle, vp(text_ptr), nbytes, min(off, nbytes), ln, lng,
+            off, ln = self._window(i, nbytes)
+            rc = L.tsx_hip_shard_desc_window_device(m.handle, vp(text_ptr), nbytes, off, ln, lng,
                                                     vp(self.dsc[b].data_ptr()), self.dsc_cap, vp(self.dsc_n[b].data_ptr()),
                                                     vp(self.emit.data_ptr()), vp(self.cs.cuda_stream))
             self.ev_scan[b].record(self.cs)
@@ -346,6 +369,9 @@ class ShardedCounter:
                     late = late or (i, status)
                     break
                 nmax = max(max(counts), 1)
+                if nmax > self.dsc_cap:                             # TSX_HIP_ERANGE; the same counts on every rank
+                    late = late or (i, [-7])
+                    break
                 if self.dsc_all[i].numel() < w8 * nmax * world:
                     self.dsc_all[i] = torch.empty((w8 * nmax * world,), **i64)
                 # every GPU sends nmax descriptions: what lies behind its own count is zeroed (validity bits 0 = a strip
@@ -398,7 +424,10 @@ class ShardedCounter:
             return self._step_desc(text_ptr, nbytes)
         m, L, vp = self.m, self.m._lib, ctypes.c_void_p
         world, rank, comm = self.world, self.rank, self.comm
-        nwin = max(1, min(self.windows, (nbytes + self.win_bytes - 1) // self.win_bytes))
+        if nbytes > self.max_text_bytes:
+            raise ValueError("sharded step: text of %d bytes, the counter was made for %d" % (nbytes, self.max_text_bytes))
+        nwin = self.windows      # the same on every rank (see _step_desc)
+        self._ensure_key_buffers()
         # the caller's text may have been produced on another stream
         self.cs.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.cs):

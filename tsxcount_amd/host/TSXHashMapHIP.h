@@ -116,6 +116,9 @@ public:
         check(rc);
     }
 
+    // empties the table (the reference has no counterpart: its maps are filled once)
+    void clear() { check(tsx_hip_clear(m_pMap)); }
+
     tsx_hip_stats stats() {
         tsx_hip_stats s;
         check(tsx_hip_get_stats(m_pMap, &s));
