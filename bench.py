@@ -154,8 +154,11 @@ def self_launch(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
+    # the ranks read their options from the environment: the launcher's own parser trips over script options that
+    # abbreviate one of its own ("--l" is a prefix of --log-dir, --local-addr, ...)
+    env["TSX_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
     sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
     sys.stderr.flush()
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
@@ -197,7 +200,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded table, collectives) even at world size 1: "
                          "the only way to push the RCCL leg through its API on a 1-GPU box")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    if not argv and "TSX_BENCH_ARGV" in os.environ:      # a rank started by self_launch()
+        argv = json.loads(os.environ["TSX_BENCH_ARGV"])
+    args = ap.parse_args(argv)
 
     # One process per GPU.  Under a launcher (python -m torch.distributed.run sets WORLD_SIZE) this process is one
     # rank.  A bare `python bench.py --gpus N` with N > 1 starts the N ranks itself -- as CHILD processes, before

@@ -47,8 +47,8 @@ def fasta_of(fastq_text):
 # (there: description exchange at world sizes <= 4 -- TSX_HIP_SHARD_MODE=keys runs the key exchange on the same table)
 CASES = ((31, 17, 240, 3, "auto", "even"), (21, 15, 30, 1, "auto", "even"), (32, 19, 700, 5, "auto", "even"),
          (31, 23, 1500, 3, "auto", "even"), (31, 23, 1500, 3, "keys", "even"),
-         (31, 23, 1500, 3, "auto", "skew"), (31, 23, 1500, 3, "keys", "skew"), (25, 17, 300, 4, "auto", "skew"),
-         (31, 23, 900, 3, "auto", "fasta"), (31, 23, 900, 3, "keys", "fasta"), (27, 16, 200, 2, "auto", "fasta"))
+         (31, 23, 1500, 3, "auto", "skew"), (31, 23, 1500, 3, "keys", "skew"), (25, 17, 120, 4, "auto", "skew"),
+         (31, 23, 900, 3, "auto", "fasta"), (31, 23, 900, 3, "keys", "fasta"), (27, 16, 60, 2, "auto", "fasta"))
 for k, l, n_reads, windows, mode, shape in CASES:
     os.environ["TSX_HIP_SHARD_MODE"] = mode
     first, cnt = shard(n_reads, shape)

@@ -143,6 +143,28 @@ def test_reference_main_with_hip_subclass_check_passes(T, tmp_path):
     assert "queried kmer count: 194697" in out and "queried (Xor) kmer count: 0" in out
 
 
+@pytest.mark.parametrize("path", ["atomic", "partitioned"])
+def test_hip_against_the_reference_serial_table_k40_to_63(T, path):
+    """The HIP table against the recorded output of the reference's own serial table (tests/golden/ref_runs.json
+    "perf_runs", oracle/ref_perf_driver.cpp) for k = 40, 47, 55, 63 (two-limb keys) and 33: the sorted
+    `kmer<TAB>count` dump of the HIP table, without the k-mers the reference could not answer (its overflow walk
+    throws for k >= 40), must hash to what the reference printed.  Both insert paths."""
+    import json
+    from test_oracle import perf_case_text, perf_digest
+    runs = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_runs.json")))["perf_runs"]
+    for r in runs:
+        m = T.TSXHashMapHIP(r["l"], 0, r["k"])
+        m.set_path(path)
+        m.countFastq(perf_case_text(r))
+        kmers, counts = m.getAllKmers()
+        thrown = set(r["reference_thrown"])
+        pairs = [(T.decode(kmers[i], r["k"]).encode(), int(counts[i])) for i in range(len(kmers))]
+        pairs = [x for x in pairs if x[0].decode() not in thrown]
+        assert len(pairs) == r["reference_answered"]
+        assert perf_digest(pairs) == r["reference_sha256"], r["command"]
+        m.close()
+
+
 def test_lookup_with_slot_and_kmer_starts(T):
     """getKmerCountDebug (TSXHashMap.h:477-545) and getKmerStarts (:650-658) over the C ABI."""
     from tsxcount_amd import synth

@@ -105,6 +105,40 @@ def test_oracle_against_recorded_reference_runs():
         assert h.hexdigest() == r["oracle_counts_sha256"]
 
 
+def perf_case_text(r):
+    if r["input"] == "repeated":
+        return synth.repeated_reads_fastq(r["seed"], r["n_reads"], r["lo"], r["hi"])
+    return synth.fastq(r["seed"], 0, r["n_reads"])
+
+
+def perf_digest(pairs):
+    """sha256 over the sorted `kmer<TAB>count` lines (what oracle/_ref/ref_perf_driver prints)."""
+    h = hashlib.sha256()
+    for kmer, cnt in sorted(pairs):
+        h.update(b"%s\t%d\n" % (kmer, cnt))
+    return h.hexdigest()
+
+
+def test_oracle_against_the_reference_serial_table_k40_to_63():
+    """ref_runs.json "perf_runs": the reference's OWN serial table (TSXHashMapPerf::addKmer / getKmerCount(kmer),
+    driven by oracle/ref_perf_driver.cpp over the reference's reader and fromSequence) counted these texts at
+    k = 40, 47, 55, 63 (and 33); the sha256 of its sorted `kmer<TAB>count` output is recorded.  It answers every
+    k-mer whose counter has not overflowed (the few that have are listed as `reference_thrown`: the reference
+    throws from its overflow walk for k >= 40).  The restatement must give exactly that output."""
+    import tsxcount_amd as T
+    runs = json.load(open(os.path.join(GOLDEN, "ref_runs.json")))["perf_runs"]
+    assert sorted({r["k"] for r in runs}) == [33, 40, 47, 55, 63]
+    for r in runs:
+        o = Oracle(r["k"], r["l"], r["s"], seed=1)
+        o.count_fastq(perf_case_text(r))
+        kmers, counts = o.dump()
+        thrown = set(r["reference_thrown"])
+        pairs = [(T.decode(kmers[i], r["k"]).encode(), int(counts[i])) for i in range(len(kmers))]
+        pairs = [x for x in pairs if x[0].decode() not in thrown]
+        assert len(pairs) == r["reference_answered"]
+        assert perf_digest(pairs) == r["reference_sha256"], r["command"]
+
+
 def test_fasta_records_two_lines_per_record():
     """FASTXreader<FASTAEntry> (FastXReader.h:97-116): every two non-empty lines are a record, the second is
     the sequence.  The restatement against an independent dictionary count."""

@@ -50,6 +50,22 @@ def fastq(seed, first_read, n_reads):
     return b"".join(parts)
 
 
+def repeated_reads_fastq(seed, n_reads, lo, hi, max_copies=3):
+    """Random reads of lo..hi-1 bases without poly-A tails; read i is written 1 + i % max_copies times, so every
+    k-mer count stays small (<= max_copies unless two random reads share a k-mer): inputs for narrow counters
+    that must not overflow."""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts, r = [], 0
+    for i in range(n_reads):
+        n = int(rng.integers(lo, hi))
+        s = lut[rng.integers(0, 4, size=n)].tobytes()
+        for _ in range(1 + i % max_copies):
+            parts.append(b"@r%d\n" % r + s + b"\n+\n" + b"I" * n + b"\n")
+            r += 1
+    return b"".join(parts)
+
+
 def zipf_fastq(seed, n_reads, read_len, n_templates, k, a=1.2):
     """Zipf-skewed reads: each read is a window of one of n_templates template
     sequences picked with Zipf(a) rank weights, so a few k-mers are extremely
