@@ -314,6 +314,41 @@ int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *
                               void *stream);
 
 /*
+ * The multi-GPU run as ONE call from C++ (src/mains/main.cpp:404-507: one command runs the job): a group is one table per
+ * GPU of this node, driven by one host thread per GPU inside the library (csrc/tsx_multi.cpp).
+ *   group_create            ngpus tables (devices[r] = HIP ordinal of rank r, NULL = 0..ngpus-1).  comm 0 = RCCL
+ *                           (ncclCommInitAll; librccl is loaded on demand; one GPU per rank), comm 1 = device-to-device
+ *                           copies behind a barrier (ranks may share a GPU: tests of world sizes the box cannot give RCCL)
+ *   group_count_fastq_host  countKMers for N GPUs: the text is cut into ngpus shards of whole records (empty lines
+ *                           dropped, 4 or 2 lines per record: FastXReader.h:62-116,307-385), rank r counts shard r into
+ *                           its own table (tsx_hip_count_fastq_host), then group_merge
+ *   group_merge             the merge of the per-GPU tables: entries grouped by owner = tsx_hip_owner(kmer, ngpus)
+ *                           (tsx_hip_partition_device), ONE all-to-all of k-mers and counts, the owner clears and
+ *                           re-inserts (tsx_hip_add_kmers_device).  Afterwards every k-mer lives on the GPU that owns it
+ *   group_get_counts_host   getKmerCount(kmer) (TSXHashMap.h:548-638): every k-mer is asked of its owner
+ *   group_get_stats         sums over the GPUs (distinct = getKmerCount(), TSXHashMap.h:645)
+ * tsx_hip_group_map gives the table of one rank for everything else in this header.
+ */
+typedef struct tsx_hip_group tsx_hip_group;
+int tsx_hip_group_create(tsx_hip_group **out, int ngpus, const int *devices, int k, int l, int storagebits,
+                         int overflow_l, uint64_t hash_seed, int comm);
+void tsx_hip_group_destroy(tsx_hip_group *g);
+int tsx_hip_group_size(const tsx_hip_group *g);
+tsx_hip_map *tsx_hip_group_map(tsx_hip_group *g, int rank);
+const char *tsx_hip_group_comm_name(const tsx_hip_group *g);   /* "rccl" or "copy" */
+const char *tsx_hip_group_last_error(void);
+int tsx_hip_group_set_record_lines(tsx_hip_group *g, int lines);
+int tsx_hip_group_clear(tsx_hip_group *g);
+int tsx_hip_group_count_fastq_host(tsx_hip_group *g, const char *text, size_t n);
+int tsx_hip_group_merge(tsx_hip_group *g);
+int tsx_hip_group_get_counts_host(tsx_hip_group *g, const uint64_t *kmers, size_t n, uint64_t *counts_out);
+int tsx_hip_group_get_stats(tsx_hip_group *g, tsx_hip_stats *out);
+uint64_t tsx_hip_group_exchanged_entries(const tsx_hip_group *g);   /* entries that changed GPU in the last merge */
+/* Where group_count_fastq_host cuts a text: cuts_out[0 .. parts], shard i = [cuts_out[i], cuts_out[i + 1]); every cut is
+ * a record boundary of the reference's reader.  Host logic only (no GPU). */
+int tsx_hip_cut_records_host(const char *text, size_t n, int parts, int lines_per_record, size_t *cuts_out);
+
+/*
  * Synthetic reads shaped like generateFakeSequences.py (500-1000 random bases
  * + 100-300 'A', '@seq<i>' header, '&' qualities), written as FASTQ text
  * straight into device memory.  Sizing call: dev_out == NULL returns the byte

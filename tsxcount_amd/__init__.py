@@ -119,6 +119,24 @@ def lib():
     L.tsx_hip_set_path.argtypes = [vp, ci]
     L.tsx_hip_set_record_lines.argtypes = [vp, ci]
     L.tsx_hip_synth_fastq_device.argtypes = [u64, u64, u64, ci, vp, sz, u64p, u64p, u64p, ci, vp]
+    L.tsx_hip_group_create.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(ci), ci, ci, ci, ci, u64, ci]
+    L.tsx_hip_group_destroy.argtypes = [vp]
+    L.tsx_hip_group_destroy.restype = None
+    L.tsx_hip_group_size.argtypes = [vp]
+    L.tsx_hip_group_map.argtypes = [vp, ci]
+    L.tsx_hip_group_map.restype = vp
+    L.tsx_hip_group_comm_name.argtypes = [vp]
+    L.tsx_hip_group_comm_name.restype = ctypes.c_char_p
+    L.tsx_hip_group_last_error.restype = ctypes.c_char_p
+    L.tsx_hip_group_set_record_lines.argtypes = [vp, ci]
+    L.tsx_hip_group_clear.argtypes = [vp]
+    L.tsx_hip_group_count_fastq_host.argtypes = [vp, ctypes.c_char_p, sz]
+    L.tsx_hip_group_merge.argtypes = [vp]
+    L.tsx_hip_group_get_counts_host.argtypes = [vp, u64p, sz, u64p]
+    L.tsx_hip_group_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.tsx_hip_group_exchanged_entries.argtypes = [vp]
+    L.tsx_hip_group_exchanged_entries.restype = u64
+    L.tsx_hip_cut_records_host.argtypes = [ctypes.c_char_p, sz, ci, ci, ctypes.POINTER(sz)]
     _lib = L
     return L
 
@@ -356,6 +374,70 @@ class TSXHashMapHIP:
         for i, it in enumerate(items):
             out[i] = encode(it, self.k) if isinstance(it, (str, bytes)) else np.asarray(it, dtype=np.uint64)
         return out
+
+
+def cut_records(text, parts, lines_per_record=4):
+    """Where the multi-GPU host cuts a text: parts + 1 offsets, every one a record boundary of the reference's reader."""
+    b = bytes(text)
+    out = (ctypes.c_size_t * (parts + 1))()
+    _check(lib().tsx_hip_cut_records_host(b, len(b), parts, lines_per_record, out))
+    return [int(x) for x in out]
+
+
+class TSXHashMapHIPGroup:
+    """One table per GPU of this node behind one object (tsx_hip_group_*, csrc/tsx_multi.cpp): countFastq cuts the text
+    into record shards, every GPU counts its own, the tables are merged (comm "rccl": RCCL, one GPU per rank; "copy":
+    device copies, ranks may share a GPU), lookups go to the owner of each k-mer."""
+
+    def __init__(self, gpus, iL, iStorageBits, iK, hash_seed=1, devices=None, comm="rccl"):
+        self._lib = lib()
+        self._h = ctypes.c_void_p()
+        dv = (ctypes.c_int * gpus)(*devices) if devices is not None else None
+        rc = self._lib.tsx_hip_group_create(ctypes.byref(self._h), gpus, dv, iK, iL, iStorageBits, 0, hash_seed,
+                                            {"rccl": 0, "copy": 1}[comm])
+        self._check(rc)
+        self.k, self.wk, self.gpus = iK, key_limbs(iK), gpus
+
+    def _check(self, rc):
+        if rc != OK:
+            raise TSXException(rc, self._lib.tsx_hip_strerror(rc).decode() + " (" + self._lib.tsx_hip_group_last_error().decode() + ")")
+
+    def close(self):
+        if self._h:
+            self._lib.tsx_hip_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def comm_name(self):
+        return self._lib.tsx_hip_group_comm_name(self._h).decode()
+
+    def set_record_lines(self, lines):
+        self._check(self._lib.tsx_hip_group_set_record_lines(self._h, lines))
+
+    def clear(self):
+        self._check(self._lib.tsx_hip_group_clear(self._h))
+
+    def countFastq(self, data):
+        b = bytes(data)
+        self._check(self._lib.tsx_hip_group_count_fastq_host(self._h, b, len(b)))
+
+    def getKmerCounts(self, kmers):
+        k = np.ascontiguousarray(np.asarray(kmers, dtype=np.uint64).reshape(-1, self.wk))
+        out = np.zeros(k.shape[0], dtype=np.uint64)
+        self._check(self._lib.tsx_hip_group_get_counts_host(self._h, _p(k), k.shape[0], _p(out)))
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(self._lib.tsx_hip_group_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def rank_stats(self, rank):
+        s = Stats()
+        _check(self._lib.tsx_hip_get_stats(self._lib.tsx_hip_group_map(self._h, rank), ctypes.byref(s)))
+        return s.as_dict()
+
+    def exchanged_entries(self):
+        return int(self._lib.tsx_hip_group_exchanged_entries(self._h))
 
 
 def bgzf_index(gz):

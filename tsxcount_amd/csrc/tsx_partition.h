@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                                                                      const unsigned long long *list_start,
                                                                      const unsigned long long *list_cnt,
                                                                      uint64_t list_cap, uint32_t pieces, uint32_t nseg,
-                                                                     int dbg_arg, int fresh, int prefetch, int look_ahead) {
+                                                                     int dbg_arg, int fresh, int look_ahead) {
     const int dbg = DIAG ? dbg_arg : 0;
     extern __shared__ uint64_t s_seg[];  // 2^S slots, then four batches of 64 keys per wave
     const uint32_t nslots = 1u << p.S;
@@ -1555,7 +1555,6 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
 
 
     uint64_t B[BK];
-    uint32_t pf = 0;   // the dword this lane prefetched for the next segment
     // The first batches of the NEXT segment are loaded as soon as this wave's stream is dry (the batch registers
     // are free then) and arrive while the wave probes for its last keys and the segment is written out: a segment
     // costs ~23 us, of which the list sizes (scalar loads) and the keys (one HBM latency) used to be waited for
@@ -1564,7 +1563,6 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
     uint64_t nx_n = 0;
     const uint64_t *nx_base = nullptr;
     for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        asm volatile("" ::"v"(pf));   // the prefetch is 'used' here, a segment after it was issued
         const bool have = (nx_seg == seg);
         uint32_t sizes = 0;
         if (!have) sizes = list_sizes(seg);
@@ -1612,16 +1610,6 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
             ring[64u + lane] = B[1];
             ring[128u + lane] = B[2];
             ring[192u + lane] = B[3];
-            if (pass == 0) {
-                // (optional, off: the next segment's lists towards L2 -- the key lists are then read twice)
-                const uint32_t nseg2 = seg + gridDim.x;
-                if (prefetch && nseg2 < nseg) {
-                    const uint64_t *base2;
-                    const uint32_t mine2 = my_list(nseg2, sizes2, base2);
-                    const uint32_t line = (wi * 64u + lane) * 16u;             // first key of this lane's line
-                    if (line < mine2) pf = *reinterpret_cast<const uint32_t *>(base2 + line);
-                }
-            }
             // The loop is bound by instruction issue (16 waves share 4 SIMDs: every instruction of the round costs
             // the round ~8 cycles; the LDS pipe would allow ~430 cycles per round, scripts/lds_cas_chain.hip), so it
             // is kept lean: a lane's state is (e0, q, i) with i == 0 meaning "holds no key"; nothing else lives
@@ -1661,9 +1649,9 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                 if (nm) {
                     const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-                    const uint32_t pp = off + pre;   // relative to batch cb: 0..126
+                    // stream position cb * 64 + off + pre, modulo the ring's 256 words (batch b sits in quarter b & 3):
                     // consecutive stream positions = consecutive words of the ring: no bank conflicts
-                    const uint64_t kf = ring[(((cb + (pp >> 6)) & 3u) << 6) + (pp & 63u)];
+                    const uint64_t kf = ring[(((cb << 6) + off) + pre) & 255u];
                     if (i == 0u && taken + pre < total) {
                         i = 1u;
                         q = ((uint32_t)kf + 1u) & smask;                    // q_1 = q_0 + 1

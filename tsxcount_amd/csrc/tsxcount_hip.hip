@@ -895,23 +895,19 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         const size_t seg_bytes = ((size_t)8 << p.S) * p.W;
         static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
         if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
-        static int build_pf = -1;   // TSX_HIP_BUILD_PREFETCH=0|1: pull the next segment's lists towards L2 during the insert
-        // off by default: it saves 0.1 ms of 6.3 but the prefetched lines rarely survive in L2 until they are
-        // used -- the key lists are then read from HBM twice (12.6 GB instead of 6.5 GB, profiles/README.md)
-        if (build_pf < 0) { const char *e = getenv("TSX_HIP_BUILD_PREFETCH"); build_pf = e ? atoi(e) : 0; }
         static int build_la = -1;   // TSX_HIP_BUILD_LOOKAHEAD=0|1: the tail's look-ahead over the next probe positions
         if (build_la < 0) { const char *e = getenv("TSX_HIP_BUILD_LOOKAHEAD"); build_la = e ? atoi(e) : 1; }
         if (p.wk == 1 && p.W == 1 && build_v == 2) {
             if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
                 hipLaunchKernelGGL((build_segments_stream_kernel<true>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_pf, build_la);
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_la);
             else {
                 // TSX_HIP_BUILD_SNT: threads per workgroup of the stream build (1024; 512 with TSX_HIP_SEG_BITS=13 puts two
                 // workgroups on a CU: 64 KiB segment + 16 KiB of rings each)
                 int snt = 1024;
                 if (const char *e = getenv("TSX_HIP_BUILD_SNT")) snt = std::min(1024, std::max(64 * (int)pieces, atoi(e) & ~63));
                 hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(snt), seg_bytes + (size_t)(snt / 64) * 2048, st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_pf, build_la);
+                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_la);
             }
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,

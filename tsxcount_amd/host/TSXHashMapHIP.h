@@ -155,4 +155,63 @@ private:
     const uint8_t m_iThreads;
 };
 
+// The same surface over the GPUs of one node (tsx_hip_group_*, csrc/tsx_multi.cpp): reads shard across the GPUs,
+// the per-GPU tables are merged over RCCL, every k-mer then lives on the GPU that owns it.
+class TSXHashMapHIPGroup {
+public:
+    // piDevices: HIP ordinal per rank (nullptr: 0 .. iGpus-1); iComm 0 = RCCL, 1 = device copies (ranks may share a GPU)
+    TSXHashMapHIPGroup(int iGpus, const int *piDevices, uint8_t iL, uint32_t iStorageBits, uint16_t iK, uint64_t iHashSeed = 1,
+                       int iComm = 0)
+        : m_iK(iK) {
+        check(tsx_hip_group_create(&m_pGroup, iGpus, piDevices, iK, iL, (int)iStorageBits, 0, iHashSeed, iComm));
+        check(tsx_hip_get_layout(tsx_hip_group_map(m_pGroup, 0), &m_oLayout));
+        std::cerr << "Creating " << iGpus << " arrays with " << m_oLayout.table_bytes << " bytes for " << m_oLayout.slots
+                  << " places each (" << tsx_hip_group_comm_name(m_pGroup) << " merge)." << std::endl;
+    }
+    ~TSXHashMapHIPGroup() { tsx_hip_group_destroy(m_pGroup); }
+    TSXHashMapHIPGroup(const TSXHashMapHIPGroup &) = delete;
+    TSXHashMapHIPGroup &operator=(const TSXHashMapHIPGroup &) = delete;
+
+    const tsx_hip_layout &getLayout() const { return m_oLayout; }
+    int size() const { return tsx_hip_group_size(m_pGroup); }
+    void setRecordLines(int iLines) { check(tsx_hip_group_set_record_lines(m_pGroup, iLines)); }
+    void clear() { check(tsx_hip_group_clear(m_pGroup)); }
+    // countKMers (main.cpp:104-218) over all GPUs + the merge of the tables
+    void countFastq(const char *pText, size_t iBytes) { check(tsx_hip_group_count_fastq_host(m_pGroup, pText, iBytes)); }
+    void getKmerCounts(const std::vector<uint64_t> &limbs, size_t n, std::vector<uint64_t> &out) {
+        out.resize(n);
+        check(tsx_hip_group_get_counts_host(m_pGroup, limbs.data(), n, out.data()));
+    }
+    tsx_kmer_t fromSequence(const std::string &seq) const {
+        tsx_kmer_t out(m_oLayout.key_limbs);
+        if (tsx_hip_encode(seq.c_str(), m_iK, out.data()) != TSX_HIP_OK) throw TSXException("bad k-mer", TSX_HIP_EINVAL);
+        return out;
+    }
+    tsx_hip_stats stats() {
+        tsx_hip_stats s;
+        check(tsx_hip_group_get_stats(m_pGroup, &s));
+        return s;
+    }
+    uint64_t exchangedEntries() const { return tsx_hip_group_exchanged_entries(m_pGroup); }
+    void print_stats() {
+        tsx_hip_stats s = stats();
+        std::cerr << "Used fields: " << s.distinct << std::endl;
+        std::cerr << "Available fields: " << (double)m_oLayout.slots * size() << std::endl;
+        std::cerr << "k=" << m_iK << " l=" << m_oLayout.l << " x " << size() << " GPUs, entry limbs=" << m_oLayout.entry_limbs
+                  << " storage bits=" << m_oLayout.count_bits << std::endl;
+    }
+
+private:
+    static void check(int rc) {
+        if (rc == TSX_HIP_OK) return;
+        std::string msg = tsx_hip_strerror(rc);
+        const std::string why = tsx_hip_group_last_error();
+        if (!why.empty()) msg += " (" + why + ")";
+        throw TSXException(msg, rc);
+    }
+    tsx_hip_group *m_pGroup = nullptr;
+    tsx_hip_layout m_oLayout;
+    const uint32_t m_iK;
+};
+
 #endif  // TSXCOUNT_TSXHASHMAPHIP_H

@@ -25,6 +25,10 @@ struct arguments {
     bool check = false, checkabort = false;
     unsigned long long seed = 1;
     int device = 0;
+    bool group = false;           // --gpus given: the group path, even for one GPU (its merge then runs through RCCL with one rank)
+    int gpus = 1;                 // --gpus N: reads shard across N GPUs, per-GPU tables merged over RCCL
+    std::string comm = "rccl";    // --comm=rccl|copy (copy: device-to-device copies, ranks may share a GPU)
+    std::vector<int> devices;     // --devices=a,b,...: HIP ordinal per rank (default 0 .. N-1)
 };
 
 static bool opt(const char *arg, const char *name, std::string &val) {
@@ -37,6 +41,7 @@ static bool opt(const char *arg, const char *name, std::string &val) {
 static int usage() {
     std::cerr << "Usage: tsxCount --input=FASTQ|FASTA[.gz] [--k=K] [--l=L] [--s=STORAGE] [--mode=HIP] [--threads=T]\n"
                  "                [--check] [--checkabort] [--seed=S] [--device=D] [--format=fastq|fasta]\n"
+                 "                [--gpus=N [--comm=rccl|copy] [--devices=a,b,...]]\n"
                  "Count k-mers on an MI355X. --check compares with FASTQ.<k>.count (kmer<TAB>count per line)."
               << std::endl;
     return 1;
@@ -57,13 +62,13 @@ static bool read_gz(const std::string &path, std::vector<char> &owned) {
 // test): a blocked gzip file (BGZF) is mmap'ed as it is and inflated on the GPU (bgzf = true), any other gzip
 // stream goes through zlib here
 static bool load_input(const std::string &path, std::vector<char> &owned, const char *&text, size_t &n, void *&map,
-                       bool &bgzf) {
+                       bool &bgzf, bool allow_bgzf) {
     map = nullptr;
     bgzf = false;
     if (path.size() > 3 && path.rfind(".gz") == path.size() - 3) {
         int zfd = open(path.c_str(), O_RDONLY);
         struct stat zst;
-        if (zfd >= 0 && fstat(zfd, &zst) == 0 && zst.st_size > 0) {
+        if (allow_bgzf && zfd >= 0 && fstat(zfd, &zst) == 0 && zst.st_size > 0) {
             void *zm = mmap(nullptr, (size_t)zst.st_size, PROT_READ, MAP_PRIVATE, zfd, 0);
             if (zm != MAP_FAILED) {
                 size_t members = 0, tb = 0;
@@ -95,6 +100,96 @@ static bool load_input(const std::string &path, std::vector<char> &owned, const 
     return true;
 }
 
+static bool is_fasta(const arguments &a) {   // FASTA (two lines per record, FASTXreader<FASTAEntry>) by option or by file name
+    std::string stem = a.input_path;
+    if (stem.size() > 3 && stem.rfind(".gz") == stem.size() - 3) stem.resize(stem.size() - 3);
+    auto ends = [&](const char *suf) { const std::string x(suf); return stem.size() >= x.size() && stem.compare(stem.size() - x.size(), x.size(), x) == 0; };
+    return a.format == "fasta" || (a.format.empty() && (ends(".fa") || ends(".fasta") || ends(".fna")));
+}
+
+// "Added a total of ..." and the --check of main.cpp:224-396, for one table or a group of them
+template <typename Map>
+static int report_and_check(Map &oMap, const arguments &a, double dt) {
+    tsx_hip_stats st = oMap.stats();
+    std::cout << "Added a total of " << st.distinct << " different kmers" << std::endl;
+    std::cerr << "add calls: " << st.kmers_added << std::endl;
+    std::cerr << "count time [s]: " << dt << " (" << (dt > 0 ? st.kmers_added / dt : 0) << " k-mers/s, host to table)"
+              << std::endl;
+    int rc = 0;
+    if (a.check) {  // main.cpp:224-396
+        std::string sRefFilename = a.input_path + "." + std::to_string(a.k) + ".count";
+        std::cout << "Checking kmer counts against manual hashmap ..." << std::endl;
+        std::cerr << "Loading reference file: " << sRefFilename << std::endl;
+        std::ifstream file(sRefFilename);
+        if (!file.is_open()) {
+            std::cerr << "Could not open " << sRefFilename << std::endl;
+            return 4;
+        }
+        std::vector<uint64_t> limbs, expect, got;
+        std::vector<std::string> names;
+        std::string line;
+        uint64_t iRefCount = 0, totalerrors = 0;
+        auto flush = [&]() {
+            if (expect.empty()) return;
+            oMap.getKmerCounts(limbs, expect.size(), got);
+            for (size_t i = 0; i < expect.size(); ++i)
+                if (got[i] != expect[i]) {
+                    ++totalerrors;
+                    if (totalerrors <= 20)
+                        std::cout << "kmer: ( " << names[i] << " ): " << got[i] << " Should be " << expect[i] << std::endl;
+                    if (a.checkabort) exit(200);  // main.cpp:285-291
+                }
+            std::cout << "Checked " << expect.size() << " kmers" << std::endl;
+            iRefCount += expect.size();
+            limbs.clear(); expect.clear(); names.clear();
+        };
+        while (std::getline(file, line)) {
+            size_t tab = line.find('\t');
+            if (tab == std::string::npos) continue;
+            std::string kmer = line.substr(0, tab);
+            if ((int)kmer.size() != a.k) continue;
+            tsx_kmer_t enc = oMap.fromSequence(kmer);
+            limbs.insert(limbs.end(), enc.begin(), enc.end());
+            expect.push_back(strtoull(line.c_str() + tab + 1, nullptr, 10));
+            names.push_back(kmer);
+            if (expect.size() >= 100000) flush();  // main.cpp:263
+        }
+        flush();
+        std::cout << "total errors" << totalerrors << std::endl;
+        std::cout << "Kmer count check completed." << std::endl;
+        std::cout << "Reference kmer count: " << iRefCount << std::endl;
+        std::cout << "tsxCount kmer count: " << st.distinct << std::endl;
+        if (totalerrors || iRefCount != st.distinct) rc = 5;
+    }
+    oMap.print_stats();
+    return rc;
+}
+
+// --gpus N: one table per GPU, the text cut into N shards of whole records, the tables merged over RCCL
+// (tsx_hip_group_*); --check asks every k-mer of the GPU that owns it
+static int run_group(const arguments &a) {
+    std::cerr << "Creating TSXHashMap HIP on " << a.gpus << " GPUs" << std::endl;
+    TSXHashMapHIPGroup oGroup(a.gpus, a.devices.empty() ? nullptr : a.devices.data(), (uint8_t)a.l, (uint32_t)a.storagebits,
+                              (uint16_t)a.k, a.seed, a.comm == "copy" ? 1 : 0);
+    if (is_fasta(a)) { oGroup.setRecordLines(2); std::cerr << "Format=FASTA (2 lines per record)" << std::endl; }
+    std::vector<char> owned;
+    const char *text = nullptr;
+    size_t n = 0;
+    void *map = nullptr;
+    bool bgzf = false;
+    // (.gz: inflated by zlib on the host, as the reference's reader does -- the record cuts need the text)
+    if (!load_input(a.input_path, owned, text, n, map, bgzf, false)) {
+        std::cerr << "Could not read " << a.input_path << std::endl;
+        return 3;
+    }
+    auto t0 = std::chrono::steady_clock::now();
+    oGroup.countFastq(text, n);
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (map) munmap(map, n);
+    std::cerr << "entries moved between GPUs by the merge: " << oGroup.exchangedEntries() << std::endl;
+    return report_and_check(oGroup, a, dt);
+}
+
 int main(int argc, char *argv[]) {
     arguments a;
     for (int i = 1; i < argc; ++i) {
@@ -110,6 +205,16 @@ int main(int argc, char *argv[]) {
         else if (opt(argv[i], "seed", v)) a.seed = strtoull(v.c_str(), nullptr, 10);
         else if (opt(argv[i], "format", v)) a.format = v;
         else if (opt(argv[i], "device", v)) a.device = atoi(v.c_str());
+        else if (opt(argv[i], "gpus", v)) { a.gpus = atoi(v.c_str()); a.group = true; }
+        else if (opt(argv[i], "comm", v)) a.comm = v;
+        else if (opt(argv[i], "devices", v)) {
+            for (size_t at = 0; at < v.size();) {
+                const size_t c = v.find(',', at);
+                a.devices.push_back(atoi(v.substr(at, c == std::string::npos ? c : c - at).c_str()));
+                if (c == std::string::npos) break;
+                at = c + 1;
+            }
+        }
         else if (opt(argv[i], "help", v)) return usage();
         else if (argv[i][0] == '-') { std::cerr << "unknown option " << argv[i] << std::endl; return usage(); }
     }
@@ -130,23 +235,18 @@ int main(int argc, char *argv[]) {
         return 2;
     }
 
+    if (a.gpus < 1 || (a.comm != "rccl" && a.comm != "copy") || (!a.devices.empty() && (int)a.devices.size() != a.gpus)) return usage();
     try {
+        if (a.group) return run_group(a);
         std::cerr << "Creating TSXHashMap HIP" << std::endl;
         TSXHashMapHIP oMap((uint8_t)a.l, (uint32_t)a.storagebits, (uint16_t)a.k, (uint8_t)a.threads, a.seed, a.device);
-
-        {   // FASTA (two lines per record, FASTXreader<FASTAEntry>) by option or by file name
-            std::string stem = a.input_path;
-            if (stem.size() > 3 && stem.rfind(".gz") == stem.size() - 3) stem.resize(stem.size() - 3);
-            auto ends = [&](const char *suf) { const std::string x(suf); return stem.size() >= x.size() && stem.compare(stem.size() - x.size(), x.size(), x) == 0; };
-            const bool fasta = a.format == "fasta" || (a.format.empty() && (ends(".fa") || ends(".fasta") || ends(".fna")));
-            if (fasta) { oMap.setRecordLines(2); std::cerr << "Format=FASTA (2 lines per record)" << std::endl; }
-        }
+        if (is_fasta(a)) { oMap.setRecordLines(2); std::cerr << "Format=FASTA (2 lines per record)" << std::endl; }
         std::vector<char> owned;
         const char *text = nullptr;
         size_t n = 0;
         void *map = nullptr;
         bool bgzf = false;
-        if (!load_input(a.input_path, owned, text, n, map, bgzf)) {
+        if (!load_input(a.input_path, owned, text, n, map, bgzf, true)) {
             std::cerr << "Could not read " << a.input_path << std::endl;
             return 3;
         }
@@ -168,62 +268,7 @@ int main(int argc, char *argv[]) {
         }
         double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (map) munmap(map, n);
-        tsx_hip_stats st = oMap.stats();
-        std::cout << "Added a total of " << st.distinct << " different kmers" << std::endl;
-        std::cerr << "add calls: " << st.kmers_added << std::endl;
-        std::cerr << "count time [s]: " << dt << " (" << (dt > 0 ? st.kmers_added / dt : 0) << " k-mers/s, host to table)"
-                  << std::endl;
-
-        int rc = 0;
-        if (a.check) {  // main.cpp:224-396
-            std::string sRefFilename = a.input_path + "." + std::to_string(a.k) + ".count";
-            std::cout << "Checking kmer counts against manual hashmap ..." << std::endl;
-            std::cerr << "Loading reference file: " << sRefFilename << std::endl;
-            std::ifstream file(sRefFilename);
-            if (!file.is_open()) {
-                std::cerr << "Could not open " << sRefFilename << std::endl;
-                return 4;
-            }
-            const size_t wk = (size_t)oMap.getLayout().key_limbs;
-            std::vector<uint64_t> limbs, expect, got;
-            std::vector<std::string> names;
-            std::string line;
-            uint64_t iRefCount = 0, totalerrors = 0;
-            auto flush = [&]() {
-                if (expect.empty()) return;
-                oMap.getKmerCounts(limbs, expect.size(), got);
-                for (size_t i = 0; i < expect.size(); ++i)
-                    if (got[i] != expect[i]) {
-                        ++totalerrors;
-                        if (totalerrors <= 20)
-                            std::cout << "kmer: ( " << names[i] << " ): " << got[i] << " Should be " << expect[i] << std::endl;
-                        if (a.checkabort) exit(200);  // main.cpp:285-291
-                    }
-                std::cout << "Checked " << expect.size() << " kmers" << std::endl;
-                iRefCount += expect.size();
-                limbs.clear(); expect.clear(); names.clear();
-            };
-            while (std::getline(file, line)) {
-                size_t tab = line.find('\t');
-                if (tab == std::string::npos) continue;
-                std::string kmer = line.substr(0, tab);
-                if ((int)kmer.size() != a.k) continue;
-                tsx_kmer_t enc = oMap.fromSequence(kmer);
-                limbs.insert(limbs.end(), enc.begin(), enc.end());
-                expect.push_back(strtoull(line.c_str() + tab + 1, nullptr, 10));
-                names.push_back(kmer);
-                if (expect.size() >= 100000) flush();  // main.cpp:263
-            }
-            (void)wk;
-            flush();
-            std::cout << "total errors" << totalerrors << std::endl;
-            std::cout << "Kmer count check completed." << std::endl;
-            std::cout << "Reference kmer count: " << iRefCount << std::endl;
-            std::cout << "tsxCount kmer count: " << st.distinct << std::endl;
-            if (totalerrors || iRefCount != st.distinct) rc = 5;
-        }
-        oMap.print_stats();
-        return rc;
+        return report_and_check(oMap, a, dt);
     } catch (const TSXException &e) {
         std::cerr << "TSXException: " << e.what() << std::endl;
         return e.code() == TSX_HIP_EFULL ? 42 : 10;  // exit(42): TSXHashMap.h:340-343
