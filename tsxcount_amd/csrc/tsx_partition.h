@@ -78,6 +78,15 @@ __device__ __forceinline__ void store_rec(uint64_t *ptr, const uint64_t (&r)[RW]
 constexpr uint32_t OVF_N = 64;
 constexpr uint64_t OVF_SALT = 0x5DEECE66D1CE4E5BULL;
 
+// The record level 2 leaves for build_segments_stream_kernel<.., PRE = true> (one-limb keys and slots, R + F >= 32,
+// R + F + S <= 64): the slot image of the key -- func bits above R zero bits where the reprobe count goes -- and, above
+// it, the FIRST probe position q_1 = (home + 1) mod 2^S inside the segment.  The build then needs a mask and a shift per
+// key instead of two 64-bit shifts, three ands and an add, in the loop that is bound by instruction issue.
+__device__ __forceinline__ uint64_t format_record(const TableParams &p, uint64_t key) {
+    const uint32_t q1 = ((uint32_t)key + 1u) & (uint32_t)p.seg_mask;
+    return ((key >> p.lg) << p.R) | ((uint64_t)q1 << (p.R + p.F));
+}
+
 constexpr int PART_MAX_PIECES = 512;   // pieces of a source region one workgroup may have to walk (src_np / cpr)
 constexpr int PART_ITER = 3;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
 template <int RW>
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap,
     const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap, int dst_bm, unsigned long long *key_sum,
-    uint32_t dst_r0, uint32_t dst_nr) {
+    uint32_t dst_r0, uint32_t dst_nr, int fmt) {
     constexpr int RPT = (PART_WPT >= RW) ? PART_WPT / RW : 1;   // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     auto put_word = [&](uint64_t w, const uint64_t *ring, uint32_t hd, uint32_t q, unsigned long long at,
                         unsigned long long lim) {
         if (dbg & 256) return;  // ablation: no stores
-        if (at + q < lim) { dst[at + q] = w; return; }
+        if (at + q < lim) { dst[at + q] = (RW == 1 && fmt) ? format_record(p, w) : w; return; }   // (fmt: see format_record)
         if ((q & (RW - 1)) == 0) {   // sub-list full: the lane that holds the record's first word spills all of it
             uint64_t rec[RW];
 #pragma unroll
@@ -336,8 +345,10 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
                     for (int t = 0; t < RW; ++t) ring[t] = cur[q][t];
                 } else if (!(dbg & 256)) {  // ring full: take the next place of the list directly
                     const unsigned long long at = atomicAdd(&s_cur[b], (unsigned long long)RW);
-                    if (at < s_lim[b]) store_rec<RW>(dst + at, cur[q]);
-                    else spill(cur[q]);
+                    if (at < s_lim[b]) {
+                        if (RW == 1 && fmt) dst[at] = format_record(p, cur[q][0]);
+                        else store_rec<RW>(dst + at, cur[q]);
+                    } else spill(cur[q]);
                 }
             }
         }
@@ -1503,7 +1514,9 @@ __device__ __forceinline__ uint32_t pass_total(uint32_t mine, uint32_t wi, uint3
     return tot;
 }
 
-template <bool DIAG>   // DIAG: the ablation / diagnostic switches of TSX_HIP_DEBUG are compiled in
+// PRE: the lists hold PRE-FORMATTED records (format_record below: level 2 wrote them that way) -- the slot image of the
+// key without reprobe count and counter, with the first probe position above it: the hand-out is a mask and a shift.
+template <bool DIAG, bool PRE>   // DIAG: the ablation / diagnostic switches of TSX_HIP_DEBUG are compiled in
 __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams p, const uint64_t *lists,
                                                                      const unsigned long long *list_start,
                                                                      const unsigned long long *list_cnt,
@@ -1528,6 +1541,11 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
     const uint64_t k0mask = p.k0mask;
     const uint32_t maxr = p.max_reprobes;
     const uint64_t one = 1ULL << p.cshift;
+    // One-limb slots: the counter is the top C <= 32 bits, so the key bits (K0 = 64 - C of them) cover the whole low
+    // dword -- the loop works on dwords: key_lo = e0_lo | i, the high dword carries the rest of the key and the counter.
+    const uint32_t one_hi = 1u << (p.cshift - 32), kmask_hi = (uint32_t)(k0mask >> 32);
+    // pre-formatted records: bits [0, rf) are the slot image (rf = R + F >= 32), bits [rf, rf + S) the first probe position
+    const uint32_t pre_qsh = (uint32_t)(p.R + p.F) - 32u, pre_emask = (1u << ((p.R + p.F) - 32)) - 1u;
 
     // Sizes of the lists of segment `seg`: lane c holds the size of piece c (one load for the wave, not one
     // after the other), seg_total adds them up, my_list picks this wave group's.
@@ -1599,7 +1617,7 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
         const uint32_t npass = ((mine + 63u) / 64u + nw * BK - 1u) / (nw * BK);   // wave-group uniform
         for (uint32_t pass = 0; pass < npass && !(dbg & 2); ++pass) {
             if (pass > 0) load_batches(base, mine, wi, nw, pass, lane, B);   // long lists only: not prefetched
-            const uint32_t total = pass_total(mine, wi, nw, pass);
+            const uint32_t total = __builtin_amdgcn_readfirstlane(pass_total(mine, wi, nw, pass));   // (a scalar, said so)
             uint32_t cb = 0, off = 0, taken = 0;    // wave-uniform: current batch, keys consumed of it, keys consumed in all
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads of the ring are done
             // the batches must have arrived: the one wait for loads of this segment, spelled out so that the
@@ -1614,25 +1632,29 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
             // the round ~8 cycles; the LDS pipe would allow ~430 cycles per round, scripts/lds_cas_chain.hip), so it
             // is kept lean: a lane's state is (e0, q, i) with i == 0 meaning "holds no key"; nothing else lives
             // across rounds, the diagnostic switches are compiled out of the production instance.
-            uint64_t e0 = 0;
+            uint32_t e0_lo = 0, e0_hi = 0;
             uint32_t i = 0, q = 0;
             unsigned long long d_rounds = 0, d_t0 = 0;
             if (DIAG && (dbg & 16)) d_t0 = __builtin_amdgcn_s_memtime();
             // one probe for every lane that holds a key
             auto probe = [&]() {
                 if (i != 0u) {
-                    const uint64_t key0 = e0 | i;
+                    const uint32_t key_lo = e0_lo | i;
                     const unsigned long long old =
-                        atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
-                    bool placed = (old == 0ULL);
-                    if (!placed && (old & k0mask) == key0) {
+                        atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL,
+                                  ((unsigned long long)(e0_hi | one_hi) << 32) | key_lo);
+                    // (no && below: a short-circuit is a branch, and this loop pays for every instruction)
+                    const uint32_t old_lo = (uint32_t)old, old_hi = (uint32_t)(old >> 32);
+                    const bool empty = (old == 0ULL);
+                    const bool same = (old_lo == key_lo) & ((old_hi & kmask_hi) == e0_hi);   // key_lo != 0: same implies !empty
+                    bool placed = empty | same;
+                    if (same) {
                         const unsigned long long prev =
                             atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[q]), (unsigned long long)one);
                         const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
                         if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
-                        placed = true;
                     }
-                    if (!placed && i >= maxr) {
+                    if (!placed & (i >= maxr)) {
                         atomicAdd(&p.stats[ST_FAIL], 1ULL);
                         placed = true;
                     }
@@ -1652,12 +1674,21 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                     // stream position cb * 64 + off + pre, modulo the ring's 256 words (batch b sits in quarter b & 3):
                     // consecutive stream positions = consecutive words of the ring: no bank conflicts
                     const uint64_t kf = ring[(((cb << 6) + off) + pre) & 255u];
-                    if (i == 0u && taken + pre < total) {
+                    const uint32_t left = total - taken;   // scalar
+                    if (i == 0u && pre < left) {
                         i = 1u;
-                        q = ((uint32_t)kf + 1u) & smask;                    // q_1 = q_0 + 1
-                        e0 = ((kf >> sh_lg) << sh_r) & k0mask;              // split_key for WK = 1
+                        if (PRE) {
+                            e0_lo = (uint32_t)kf;
+                            e0_hi = (uint32_t)(kf >> 32) & pre_emask;
+                            q = (uint32_t)(kf >> 32) >> pre_qsh;                // q_1, as level 2 left it
+                        } else {
+                            q = ((uint32_t)kf + 1u) & smask;                    // q_1 = q_0 + 1
+                            const uint64_t e0 = ((kf >> sh_lg) << sh_r) & k0mask;   // split_key for WK = 1
+                            e0_lo = (uint32_t)e0;
+                            e0_hi = (uint32_t)(e0 >> 32);
+                        }
                     }
-                    const uint32_t got = min((uint32_t)__builtin_popcountll(nm), total - taken);
+                    const uint32_t got = min((uint32_t)__builtin_popcountll(nm), left);
                     taken = __builtin_amdgcn_readfirstlane(taken + got);
                     off = __builtin_amdgcn_readfirstlane(off + got);
                     if (off >= 64u) {   // batch cb is used up: its quarter of the ring takes batch cb + 4
@@ -1694,6 +1725,7 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
                 if (look_ahead && i != 0u && i + 3u < maxr) {
                     const uint32_t q1 = (q + i + 1u) & smask, q2 = (q1 + i + 2u) & smask, q3 = (q2 + i + 3u) & smask;
                     const uint64_t v0 = s_seg[q], v1 = s_seg[q1], v2 = s_seg[q2];
+                    const uint64_t e0 = ((uint64_t)e0_hi << 32) | e0_lo;
                     const bool t0 = v0 != 0 && (v0 & k0mask) != (e0 | i);
                     const bool t1 = t0 && v1 != 0 && (v1 & k0mask) != (e0 | (i + 1u));
                     const bool t2 = t1 && v2 != 0 && (v2 & k0mask) != (e0 | (i + 2u));

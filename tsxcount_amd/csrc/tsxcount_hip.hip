@@ -785,8 +785,9 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
+        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
@@ -859,7 +860,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pl.buf1, (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
                            (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0,
-                           0, (unsigned long long *)nullptr, 0u, 0u));
+                           0, (unsigned long long *)nullptr, 0u, 0u, 0));
         HIP_TRY(hipGetLastError());
     }
     }   // (fused: scan_part_kernel has left the level-1 sub-lists in buffer 1)
@@ -869,6 +870,13 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     uint64_t lists_cap = 0;
     uint32_t pieces = 1;
     uint32_t nq2 = 0;
+    static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
+    if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
+    // level 2 leaves PRE-FORMATTED records (format_record, tsx_partition.h) where the stream build of one-limb keys and
+    // slots reads them and the fields fit: slot image in bits [0, R + F), first probe position above (TSX_HIP_BUILD_PRE=0: raw keys)
+    static int pre_ok = -1;
+    if (pre_ok < 0) { const char *e = getenv("TSX_HIP_BUILD_PRE"); pre_ok = e ? atoi(e) : 1; }
+    const int pre = (pre_ok && pl.b2 && p.wk == 1 && p.W == 1 && build_v == 2 && !m->dbg && p.R + p.F >= 32 && p.R + p.F + p.S <= 64) ? 1 : 0;
     if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
         const uint32_t bits = ring_bits(pl.nb2);
         nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup (the fused scan's queues follow them)
@@ -882,7 +890,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg,
                            m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
-                           pl.G1, pl.cap1, 0, (unsigned long long *)nullptr, 0u, 0u));
+                           pl.G1, pl.cap1, 0, (unsigned long long *)nullptr, 0u, 0u, pre));
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
@@ -893,21 +901,23 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
         int bnt = 1024;
         if (const char *e = getenv("TSX_HIP_BUILD_NT")) bnt = std::min(1024, std::max(64, atoi(e) & ~63));
         const size_t seg_bytes = ((size_t)8 << p.S) * p.W;
-        static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
-        if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
         static int build_la = -1;   // TSX_HIP_BUILD_LOOKAHEAD=0|1: the tail's look-ahead over the next probe positions
         if (build_la < 0) { const char *e = getenv("TSX_HIP_BUILD_LOOKAHEAD"); build_la = e ? atoi(e) : 1; }
         if (p.wk == 1 && p.W == 1 && build_v == 2) {
             if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
-                hipLaunchKernelGGL((build_segments_stream_kernel<true>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
+                hipLaunchKernelGGL((build_segments_stream_kernel<true, false>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
                                    lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_la);
             else {
                 // TSX_HIP_BUILD_SNT: threads per workgroup of the stream build (1024; 512 with TSX_HIP_SEG_BITS=13 puts two
                 // workgroups on a CU: 64 KiB segment + 16 KiB of rings each)
                 int snt = 1024;
                 if (const char *e = getenv("TSX_HIP_BUILD_SNT")) snt = std::min(1024, std::max(64 * (int)pieces, atoi(e) & ~63));
-                hipLaunchKernelGGL((build_segments_stream_kernel<false>), dim3(gb), dim3(snt), seg_bytes + (size_t)(snt / 64) * 2048, st, pp,
-                                   lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_la);
+                if (pre)
+                    hipLaunchKernelGGL((build_segments_stream_kernel<false, true>), dim3(gb), dim3(snt), seg_bytes + (size_t)(snt / 64) * 2048, st, pp,
+                                       lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_la);
+                else
+                    hipLaunchKernelGGL((build_segments_stream_kernel<false, false>), dim3(gb), dim3(snt), seg_bytes + (size_t)(snt / 64) * 2048, st, pp,
+                                       lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_la);
             }
         } else if (p.wk == 1 && p.W == 1) {
             hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
@@ -1312,7 +1322,7 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
                            (uint32_t)g, 1u, pl.buf1, (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits,
                            m->dbg, m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum, 0u, (uint32_t)g);
+                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum, 0u, (uint32_t)g, 0);
     } else {
         hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, keys, (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1),
                            pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
@@ -1395,7 +1405,7 @@ extern "C" int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_ke
                        pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits, m->dbg,
                        m->d_ovq + ((size_t)nq2 + (size_t)window * rw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)window * rw, OVQ_CAP,
                        (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, (unsigned long long *)dev_key_sum,
-                       window * rw, g1);
+                       window * rw, g1, 0);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
@@ -1556,7 +1566,7 @@ extern "C" int tsx_hip_shard_filter_device(tsx_hip_map *m, const void *dev_desc,
                        pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits, m->dbg,
                        m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP,
                        (const unsigned long long *)lp.c_log, (uint32_t)greg, lp.log_cap, 1, (unsigned long long *)nullptr, slot,
-                       nslots);
+                       nslots, 0);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
