@@ -129,7 +129,7 @@ def run_check(args, m, T, TD, dist, torch, dist_on, sharded, world, rank, red, d
     ok = ok and detail["sample"]["below_sample_multiplicity"] == 0 and detail["sample"]["safe_unequal"] == 0 \
         and detail["sample"]["looked_up"] > 0
     # second table through the other insert path (single table only)
-    if not dist_on and not args.no_cross_check:
+    if not dist_on and not args.no_cross_check and m.layout.table_bytes <= (32 << 30):   # (a second table of that size)
         other = "partitioned" if args.path == "atomic" else "atomic"
         detail["cross"] = verify.cross_check(m, text.data_ptr(), nbytes, other, device=local_rank)
         ok = ok and detail["cross"]["ok"]
@@ -326,7 +326,9 @@ def main():
         # for the whole device path of a step.
         # stage times are sums over the timed calls: one call per step, or (sharded table) one scan call per window
         # plus one build call per step -- per-step figures either way
-        pieces = args.steps if sharded else max(launches, 1)
+        # (a table above 2^32 slots is built slab by slab: one timing tuple per text window and per slab, see count_slabs)
+        slab_bits = max(0, args.l - 14 - 18) if (m.wk == 1 and m.layout.entry_limbs == 1 and not dist_on) else 0
+        pieces = args.steps if (sharded or slab_bits) else max(launches, 1)
         partitioned = build_ms / pieces > 0.5
         keys_logged = st["distinct"] if partitioned else 0
         # algorithmic bytes of each stage of one launch: the scan kernel reads the
@@ -360,6 +362,11 @@ def main():
                                   if (flt == "1" or (flt == "auto" and world >= 4)) else "walk_part_kernel", world))
             stage_bytes["scan"] = nbytes + nbytes // 2 * 2          # text read; descriptions written and packed
             stage_bytes["level1"] = world * (nbytes // 2) + rec_b * keys_logged
+        if slab_bits:
+            names["scan"] = "strip_desc_kernel + desc_pack_kernel (every text window described once)"
+            names["level1"] = "walk_part_kernel with slab filter (%d slabs x all descriptions)" % (1 << slab_bits)
+            stage_bytes["scan"] = nbytes + nbytes // 2 * 2
+            stage_bytes["level1"] = (1 << slab_bits) * (nbytes // 4) + rec_b * keys_logged
         stage_ms = {k2: stage[k2] / pieces for k2 in names}
         dom = max(stage_ms, key=lambda k2: stage_ms[k2])   # the kernel a step spends most time in
         kern_ms = stage_ms[dom]
@@ -384,9 +391,10 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "rccl_ranks": (dist.get_world_size() if dist_on else 0), "backend": (dist.get_backend() if dist_on else None),
             "config": {"workload": "synthetic FASTQ (generateFakeSequences.py shape), %d reads/GPU = %d k-mers/GPU, "
-                                   "k=%d, table 2^%d slots/GPU, %s insert path%s"
+                                   "k=%d, table 2^%d slots/GPU, %s insert path%s%s"
                                    % (args.reads, kmers_rank, args.k, args.l,
                                       "partitioned" if partitioned else "atomic",
+                                      (", built in %d slabs of 2^32 slots" % (1 << slab_bits)) if slab_bits else "",
                                       ((", table sharded by slot range, strip descriptions all-gathered over RCCL, every GPU walks all and keeps what it owns"
                                         if sc._mode() == "desc" else
                                         ", table sharded by slot range, keys exchanged by one RCCL all-to-all per window") if sharded

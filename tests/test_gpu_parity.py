@@ -1028,3 +1028,69 @@ def test_sharded_counting_world_8_in_one_process(T, monkeypatch, l, mode):
     fr = np.array([(g[0] > 0).mean() for g in got])
     assert (fr > 0.4 / world).all() and (fr < 1.6 / world).all()
 
+
+
+@pytest.mark.parametrize("l,segbits,k,reads", [(25, 9, 31, 3000), (26, 10, 21, 2500), (25, 10, 32, 2000)])
+def test_tables_built_slab_by_slab(T, l, segbits, k, reads):
+    """Tables above 2^32 slots (l - S > 18) are built slab by slab: every window of the text is described once, each
+    slab walks all descriptions with the owner filter and runs its own level 2 + build (count_slabs, tsxcount_hip.hip).
+    TSX_HIP_SLAB_SEGBITS lowers the limit so that a 2^25-slot table takes that route with 4 (l - S - segbits = 2) or 2
+    slabs; several text windows; against the oracle, against the atomic path slot range by slot range, and a second
+    count into the same (now dirty) table.  Runs in a process of its own: the limit is read once per process."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import tsxcount_amd as T
+from oracle.oracle import Oracle
+from tsxcount_amd import synth
+l, k, reads = %d, %d, %d
+text = synth.fastq(77, 0, reads)
+o = Oracle(k, 24, 4, seed=1)
+n = o.count_fastq(text)
+kmers, counts = o.dump()
+m = T.TSXHashMapHIP(l, 0, k)
+m.set_path("partitioned")
+for rep in (1, 2):
+    m.countFastq(text)
+    st = m.stats()
+    assert st["kmers_added"] == rep * n and st["distinct"] == len(kmers) and st["insert_failures"] == 0, st
+    assert st["count_sum"] == rep * n
+    assert np.array_equal(m.getKmerCounts(kmers), rep * counts)
+a = T.TSXHashMapHIP(l, 0, k)
+a.set_path("atomic")
+a.countFastq(text); a.countFastq(text)
+ka, ca = a.getAllKmers()
+km, cm = m.getAllKmers()
+ia, im = np.lexsort(ka.T[::-1]), np.lexsort(km.T[::-1])
+assert np.array_equal(ka[ia], km[im]) and np.array_equal(ca[ia], cm[im])
+m.clear()
+m.countFastq(text)
+assert np.array_equal(m.getKmerCounts(kmers), counts) and m.stats()["distinct"] == len(kmers)
+print("SLABS OK")
+''' % (ROOT, l, k, reads)
+    env = dict(os.environ, TSX_HIP_SLAB_SEGBITS=str(segbits), TSX_HIP_DEV_WINDOW=str(1 << 20))
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b"SLABS OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("l,k", [(26, 31), (25, 21)])
+def test_radix_levels_of_512_lists(T, monkeypatch, l, k):
+    """2^17 and 2^18 segments: one or both radix levels split 512 ways, their rings leave room for ONE workgroup per CU and
+    the walk / level-2 kernels run with 1024 threads (walk_part_kernel<1024>, partition_ring_kernel<1, 1024>).  Reached
+    here with 256-slot segments (TSX_HIP_SEG_BITS=8) in a 2^25 / 2^26-slot table; against the oracle."""
+    from oracle.oracle import Oracle
+    from tsxcount_amd import synth
+    monkeypatch.setenv("TSX_HIP_SEG_BITS", "8")
+    text = synth.fastq(81, 0, 2500)
+    o = Oracle(k, 23, 4, seed=1)
+    n = o.count_fastq(text)
+    kmers, counts = o.dump()
+    m = T.TSXHashMapHIP(l, 0, k)
+    m.set_path("partitioned")
+    for rep in (1, 2):
+        m.countFastq(text)
+        st = m.stats()
+        assert st["kmers_added"] == rep * n and st["distinct"] == len(kmers) and st["insert_failures"] == 0
+        assert np.array_equal(m.getKmerCounts(kmers), rep * counts)
+    m.close()

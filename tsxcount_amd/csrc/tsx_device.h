@@ -79,6 +79,9 @@ struct TableParams {
                                 // FASTXreader<FASTAEntry> reads it (two lines per record, :97-116); the sequence
                                 // is the line with (index & line_mask) == 1
     DeferList defer;            // see DeferList; set per launch by the host
+    uint64_t pos_base;          // slot number of table[0] in the table the lookups see: 0, except in the per-slab views of
+                                // a table that is built slab by slab (l - S > 18, tsxcount_hip.hip: count_slabs) -- the
+                                // secondary array is keyed by that global slot number
 };
 
 // Out of line on purpose (rare path; keeps the callers' register budgets): pk points at the kernel's own
@@ -143,6 +146,7 @@ __device__ __forceinline__ void hash_apply(const TableParams &p, LutPtr lut, con
 
 // Secondary (count overflow) array: open addressing keyed by slot position.
 __device__ inline void sec_add(const TableParams &p, uint64_t pos, uint64_t carry) {
+    pos += p.pos_base;
     uint64_t slot = mix64(pos + 0x9E3779B97F4A7C15ULL) & p.sec_mask;
     atomicAdd(&p.stats[ST_CARRY], (unsigned long long)carry);
     for (int probe = 0; probe < 256; ++probe) {

@@ -89,8 +89,11 @@ __device__ __forceinline__ uint64_t format_record(const TableParams &p, uint64_t
 
 constexpr int PART_MAX_PIECES = 512;   // pieces of a source region one workgroup may have to walk (src_np / cpr)
 constexpr int PART_ITER = 3;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
-template <int RW>
-__global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
+// NT threads: 512 where two workgroups share a CU (<= 80 KB of rings: up to 256 lists); 1024 where the rings of 512 lists
+// leave room for one workgroup only -- 16 waves per CU either way (8 waves: level 2 of a 2^18-segment table 7.5 ms per
+// 1e9 keys instead of 3.1).
+template <int RW, int NT = RING_NT>
+__global__ __launch_bounds__(NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     if (tid < 2) s_njobs[tid] = 0;
     if (tid == 0) s_ovn = 0;
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap * RW : nullptr;
-    for (uint32_t b = tid; b < nb; b += RING_NT) {
+    for (uint32_t b = tid; b < nb; b += NT) {
         s_tail[b] = 0; s_head[b] = 0;
         if (offs) { s_cur[b] = (offs_base[b] + offs[(size_t)b * nregions + r]) * RW; s_lim[b] = ~0ULL; }
         else {   // own sub-list of the destination list; dst_bm: numbered bucket-major (the lists of one bucket side by
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     // workgroup c of the region then takes pieces c, c + cpr, ... as one stream.
     const uint64_t n = src_pcnt ? 0 : (src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap));   // records
     const uint64_t region_first = src_pcnt ? 0 : (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
-    constexpr uint32_t BATCH_REC = (uint32_t)RING_NT * RPT;
+    constexpr uint32_t BATCH_REC = (uint32_t)NT * RPT;
     const uint64_t stride = (uint64_t)cpr * BATCH_REC;
 
     // TableParams is the first kernel argument: the slow paths read it from the argument segment
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         const uint32_t par = round & 1u;
         ++round;
         if (tid == 0) s_njobs[par ^ 1u] = 0;   // next round's counter: nobody reads or writes it in this round
-        for (uint32_t b = tid; b < nb; b += RING_NT) {  // (A)
+        for (uint32_t b = tid; b < nb; b += NT) {  // (A)
             const uint32_t head = s_head[b];
             const uint32_t tail = min(s_tail[b], head + CAP);  // arrivals past the ring went out directly
             const uint32_t avail = tail - head;
@@ -221,18 +224,18 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         const uint32_t oct = tid >> 3, ol = tid & 7;  // (B): an octet of lanes per job
         if (dbg & 512) return;  // ablation: bookkeeping only
         const uint32_t njobs = s_njobs[par];
-        for (uint32_t j0 = 0; j0 < njobs; j0 += PART_ITER * (RING_NT / 8)) {
+        for (uint32_t j0 = 0; j0 < njobs; j0 += PART_ITER * (NT / 8)) {
             unsigned long long meta[PART_ITER], lim[PART_ITER];
             uint32_t bj[PART_ITER];
             uint64_t k0[PART_ITER], k1[PART_ITER];
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (RING_NT / 8);
+                const uint32_t j = j0 + oct + u * (NT / 8);
                 bj[u] = (j < njobs) ? s_job[j] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < PART_ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (RING_NT / 8);
+                const uint32_t j = j0 + oct + u * (NT / 8);
                 meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
                 lim[u] = (j < njobs) ? s_lim[bj[u]] : 0ULL;
             }
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         }
     };
 
-    // A batch: record j (j = q * RING_NT + tid) comes from record index first + j, or first + j + delta once
+    // A batch: record j (j = q * NT + tid) comes from record index first + j, or first + j + delta once
     // j >= rem (a batch may run from the end of one piece into the next one); nvalid records in all.
     struct Batch { uint64_t first, delta; uint32_t rem, nvalid; };
     uint64_t base = (uint64_t)c * BATCH_REC;   // contiguous source: next batch
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     // critical path of every batch and must not go to memory
     __shared__ uint32_t s_pc[PART_MAX_PIECES];
     if (src_pcnt) {
-        for (uint32_t i = tid; c + i * cpr < src_np && i < (uint32_t)PART_MAX_PIECES; i += RING_NT)
+        for (uint32_t i = tid; c + i * cpr < src_np && i < (uint32_t)PART_MAX_PIECES; i += NT)
             s_pc[i] = (uint32_t)min((uint64_t)src_pcnt[(uint64_t)r * src_np + c + i * cpr], src_pcap);
         lds_barrier();
     }
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     auto load_batch = [&](const Batch &d, uint64_t (&regs)[RPT][RW]) {
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint32_t j = (uint32_t)q * RING_NT + tid;
+            const uint32_t j = (uint32_t)q * NT + tid;
             if (j < d.nvalid) load_rec<RW>(src + (d.first + j + (j >= d.rem ? d.delta : 0ULL)) * RW, regs[q]);
             else {
 #pragma unroll
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         uint32_t bq[RPT], slot[RPT], head[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint32_t j = (uint32_t)q * RING_NT + tid;
+            const uint32_t j = (uint32_t)q * NT + tid;
             if (key_sum && j < bc.nvalid) ksum += cur[q][0];
             bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
             slot[q] = (j < bc.nvalid) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
         for (int q = 0; q < RPT; ++q) head[q] = s_head[bq[q]];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const uint32_t j = (uint32_t)q * RING_NT + tid;
+            const uint32_t j = (uint32_t)q * NT + tid;
             if (j < bc.nvalid) {
                 const uint32_t b = bq[q];
                 if (slot[q] - head[q] < CAP) {   // RW | CAP and records are RW-aligned: a record never wraps
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(RING_NT) void partition_ring_kernel(
     flush(true, []() {});
     lds_barrier();
     if (dst_cnt)
-        for (uint32_t b = tid; b < nb; b += RING_NT) {
+        for (uint32_t b = tid; b < nb; b += NT) {
             const uint64_t li = dst_bm ? ((uint64_t)b * dst_nr + dst_r0 + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
             dst_cnt[li] = (min(s_cur[b], s_lim[b]) - li * dst_cap * RW) / RW;
         }
@@ -786,7 +789,8 @@ __global__ __launch_bounds__(256) void desc_pack_kernel(const uint4 *desc, uint6
 // the walk and ring parts of scan_part_kernel without its tile front end.  A batch = 512 strips = up to 8192 keys:
 // four flushes per batch (one per four positions), the same keys per flush as scan_part_kernel.  Workgroup g takes
 // the descriptor regions g, g + G, ... (a region = what one wave of strip_desc_kernel wrote).
-__global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
+template <int NT>   // 512 threads, two workgroups per CU (up to 256 level-1 lists); 1024 threads where 512 lists leave room for one
+__global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
                                                             const unsigned long long *desc_cnt, uint32_t nregions, int dbg,
                                                             uint64_t *dst, uint64_t dst_cap, unsigned long long *dst_cnt,
                                                             uint32_t nb, uint32_t shift, uint64_t *ovq_all,
@@ -794,8 +798,8 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
                                                             uint32_t dst_g0, uint32_t dst_gtot, int own_only,
                                                             unsigned long long *emit_sum, int long_desc, uint32_t flush_q) {
     constexpr int HOT_N = 8;
-    __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
-    __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
+    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
+    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
     __shared__ uint64_t s_roll[64];
     __shared__ uint64_t s_lut4[256];
     __shared__ uint64_t s_homh[4];
@@ -832,11 +836,11 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
         for (int grp = 0; grp < 16; ++grp) hh ^= p.roll[64 + grp * 16 + ((x >> (4 * grp)) & 15u)];
         s_homh[tid] = hh;
     }
-    if (tid < (SP_NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
+    if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
     if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
     if (tid < 2) s_njobs[tid] = 0;
     if (tid == 0) s_ovn = 0;
-    for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_th[b] = 0; }
+    for (uint32_t b = tid; b < nb; b += NT) { s_cur[b] = 0; s_th[b] = 0; }
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
     unsigned long long added = 0;   // (k-mers are counted by strip_desc_kernel)
     unsigned long long emitted = 0; // sharded runs: k-mer occurrences this GPU kept (sum over GPUs == k-mers scanned)
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
         const uint32_t par = round & 1u;
         ++round;
         if (tid == 0) s_njobs[par ^ 1u] = 0;
-        for (uint32_t b = tid; b < nb; b += SP_NT) {
+        for (uint32_t b = tid; b < nb; b += NT) {
             const unsigned long long th = s_th[b];
             const uint32_t head = (uint32_t)(th >> 32);
             const uint32_t tail = min((uint32_t)th, head + CAP);   // arrivals past the ring went out directly
@@ -895,18 +899,18 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
         const uint32_t njobs = s_njobs[par];
         // about 45 % of the lists have a line to send after a half strip: two jobs per octet and pass
         constexpr int ITER = 2;
-        for (uint32_t j0 = 0; j0 < njobs; j0 += ITER * (SP_NT / 8)) {
+        for (uint32_t j0 = 0; j0 < njobs; j0 += ITER * (NT / 8)) {
             unsigned long long meta[ITER];
             uint32_t bj[ITER];
             uint64_t k0[ITER], k1[ITER];
 #pragma unroll
             for (int u = 0; u < ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (SP_NT / 8);
+                const uint32_t j = j0 + oct + u * (NT / 8);
                 bj[u] = (j < njobs) ? s_job[j] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (SP_NT / 8);
+                const uint32_t j = j0 + oct + u * (NT / 8);
                 meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
             }
 #pragma unroll
@@ -937,8 +941,8 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     for (uint32_t r = blockIdx.x; r < nregions; r += gridDim.x) {
         const uint32_t nr = n_packed ? (uint32_t)(((uint64_t)r * desc_cap < n_packed) ? min(desc_cap, n_packed - (uint64_t)r * desc_cap) : 0ULL)
                                      : (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
-        // long descriptions (32 bytes, four strips each; a batch is SP_NT / 4 of them): lanes 4q .. 4q+3 read the same one
-        const uint32_t per = long_desc ? SP_NT / 4 : SP_NT, me = long_desc ? tid >> 2 : tid;
+        // long descriptions (32 bytes, four strips each; a batch is NT / 4 of them): lanes 4q .. 4q+3 read the same one
+        const uint32_t per = long_desc ? NT / 4 : NT, me = long_desc ? tid >> 2 : tid;
         const uint4 *rd = desc + (uint64_t)r * desc_cap * (long_desc ? 2u : 1u);
         const uint4 z4 = make_uint4(0, 0, 0, 0);
         uint4 dn = z4, dn2 = z4;
@@ -1089,10 +1093,10 @@ __global__ __launch_bounds__(SP_NT, 4) void walk_part_kernel(TableParams p, cons
     lds_barrier();
     flush(true, false);
     lds_barrier();
-    for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * dst_gtot + gl] = min(s_cur[b], cap32);
+    for (uint32_t b = tid; b < nb; b += NT) dst_cnt[(uint64_t)b * dst_gtot + gl] = min(s_cur[b], cap32);
     if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) side_insert(s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
     if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
-    if (tid < (SP_NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
+    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
     if (emit_sum) {
         for (int d = 32; d > 0; d >>= 1) emitted += __shfl_down(emitted, d, 64);
         if (lane == 0 && emitted) atomicAdd(emit_sum, emitted);

@@ -108,6 +108,8 @@ struct tsx_hip_map {
     // points): tsx_hip_clear works on the map's stream and records clear_ev behind it; every entry point that
     // launches on a caller's stream waits for that event first.  The other way round, the last caller's stream
     // is remembered (`foreign`) and tsx_hip_clear / tsx_hip_sync order themselves behind what was queued there.
+    uint8_t *d_slabdesc = nullptr;      // count_slabs: the descriptions of every text window, then one counter per window
+    size_t slabdesc_bytes = 0;
     hipEvent_t clear_ev = nullptr, join_ev = nullptr;
     bool clear_ev_set = false;
     hipStream_t foreign = nullptr;
@@ -534,7 +536,7 @@ extern "C" void tsx_hip_destroy(tsx_hip_map *m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     (void)hipFree(m->p.table); (void)hipFree(m->p.sec_keys); (void)hipFree(m->p.sec_cnt);
     drop_sh_plan(m);
-    (void)hipFree(m->sh_buf1); (void)hipFree(m->sh_cnt); (void)hipFree(m->d_desc_cnt);
+    (void)hipFree(m->sh_buf1); (void)hipFree(m->sh_cnt); (void)hipFree(m->d_desc_cnt); (void)hipFree(m->d_slabdesc);
     (void)hipFree(m->p.stats); (void)hipFree(m->d_lut); (void)hipFree(m->d_ilut); (void)hipFree(m->d_roll);
     (void)hipFree(m->d_ovq); (void)hipFree(m->d_ovq_cnt); (void)hipFree(m->d_small);
     (void)hipFree(m->d_def_rec); (void)hipFree(m->d_def_cnt); (void)hipFree(m->d_def_n);
@@ -680,10 +682,36 @@ static void drop_sh_plan(tsx_hip_map *m) { delete m->sh_pl; m->sh_pl = nullptr; 
 
 static inline int rec_words(int wk) { return wk == 3 ? 4 : wk; }
 
+// Two radix levels of at most 512 lists reach 2^18 segments (2^32 one-limb slots).  A larger table of one-limb keys and
+// slots is built SLAB BY SLAB: a slab is the 2^18 segments that share the top slab_bits() bits of the home slot -- exactly
+// what a shard of a multi-GPU table is to its GPU -- and count_slabs() walks the strip descriptions once per slab, keeping
+// the slab's keys (the owner-filtered walk of the sharded path), then runs level 2 and the build for that slab.
+static int max_seg_bits() {   // TSX_HIP_SLAB_SEGBITS: tests build small tables slab by slab
+    static int v = 0;
+    if (!v) { v = 18; if (const char *e = getenv("TSX_HIP_SLAB_SEGBITS")) v = std::min(18, std::max(9, atoi(e))); }
+    return v;
+}
+static int slab_bits(const tsx_hip_map *m) {
+    const TableParams &p = m->p;
+    const int nsegbits = p.l - p.S;
+    if (nsegbits <= max_seg_bits() || p.wk != 1 || p.W != 1 || p.lg != p.l) return 0;
+    return nsegbits - max_seg_bits();
+}
 static bool can_partition(const tsx_hip_map *m) {
     const TableParams &p = m->p;
     const int nsegbits = p.l - p.S;
-    return nsegbits >= 1 && nsegbits <= 18;  // two levels of <= 512 lists
+    if (nsegbits >= 1 && nsegbits <= (p.lg == p.l && p.wk == 1 && p.W == 1 ? max_seg_bits() : 18)) return true;  // two levels of <= 512 lists
+    const int sb = slab_bits(m);
+    return sb >= 1 && sb <= 4;
+}
+// workgroups of level 2 per level-1 bucket (plan_partition's cpr2) for the map's geometry
+static uint32_t level2_cpr(const tsx_hip_map *m) {
+    const int nsegbits = m->p.l - m->p.S;
+    const int b1 = std::min(9, (nsegbits <= 8) ? nsegbits : (nsegbits + 1) / 2);
+    if (nsegbits - b1 <= 0) return 1;
+    uint32_t c = std::min<uint32_t>(8, std::max<uint32_t>(1, (uint32_t)(m->cus * 8) / (1u << b1)));
+    while (c & (c - 1)) c &= c - 1;
+    return c;
 }
 
 template <typename T>
@@ -702,6 +730,9 @@ static int grow(hipStream_t st, T *&ptr, size_t &have, size_t need) {
 static int ensure_deferred(tsx_hip_map *m, uint64_t maxrec, hipStream_t st) {
     const int rw = rec_words(m->p.wk);
     if (!m->d_def_n) HIP_TRY(hipMalloc((void **)&m->d_def_n, 64));
+    // (passes of billions of records: room for 2^28 of them -- what lands here is hot keys with their totals and the
+    // spill of skewed lists; beyond the capacity records count as insert failures, reported by tsx_hip_sync)
+    if (maxrec > ((uint64_t)1 << 30)) maxrec = std::max<uint64_t>((uint64_t)1 << 28, maxrec / 16);
     if (maxrec > m->def_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if (m->d_def_rec) HIP_TRY(hipFree(m->d_def_rec));
@@ -784,6 +815,7 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
@@ -797,7 +829,8 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel<SP_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)walk_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
@@ -884,6 +917,17 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
             const int rco = ensure_ovq(m, (size_t)nq2 + pl.G1, rw, st);
             if (rco != TSX_HIP_OK) return rco;
         }
+        // (512 lists of one-word records: the rings leave room for one workgroup per CU -- 1024 threads then)
+        if (rw == 1 && part_lds(pl.nb2, bits) > ((size_t)80 << 10)) {
+            const uint32_t bits2 = 5;
+            hipLaunchKernelGGL((partition_ring_kernel<1, 1024>), dim3(pl.nb1 * pl.cpr2), dim3(1024),
+                               part_lds(pl.nb2, bits2), st, pp, (const uint64_t *)pl.buf1,
+                               (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
+                               pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
+                               (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits2, m->dbg,
+                               m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
+                               pl.G1, pl.cap1, 0, (unsigned long long *)nullptr, 0u, 0u, pre);
+        } else
         DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(RING_NT),
                            part_lds(pl.nb2, bits), st, pp, (const uint64_t *)pl.buf1,
                            (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
@@ -1038,7 +1082,9 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     // Which insert path?  The partitioned path rewrites every touched segment
     // once (2 x table bytes at worst), the atomic path pays ~60 ps per k-mer.
     const TableParams &p = m->p;
-    const bool use_part = shard_send || (can_partition(m) && (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes)));
+    // (a table built slab by slab takes its partitioned path in count_slabs, over the whole text at once)
+    const bool use_part = shard_send || (can_partition(m) && !slab_bits(m) &&
+                                         (m->path == 2 || (m->path == 0 && own_end * 32 >= m->lay.table_bytes)));
     if (!use_part) {
         int rcz = ensure_zeroed(m, st);
         if (rcz != TSX_HIP_OK) return rcz;
@@ -1110,10 +1156,16 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log, (unsigned long long *)nullptr, lng);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(walk_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
-                               (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
-                               (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                               (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, lng, local_fq);
+            if (lds > ((size_t)80 << 10))   // 512 lists: one workgroup per CU, 1024 threads
+                hipLaunchKernelGGL(walk_part_kernel<1024>, dim3(pl.G1), dim3(1024), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
+                                   (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                                   (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
+                                   (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, lng, local_fq);
+            else
+                hipLaunchKernelGGL(walk_part_kernel<SP_NT>, dim3(pl.G1), dim3(SP_NT), lds, st, pp, (const uint4 *)m->d_buf[0], desc_cap,
+                                   (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                                   (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
+                                   (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, lng, local_fq);
         } else {
             hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
@@ -1361,7 +1413,7 @@ extern "C" int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_ke
     PartPlan &pl = *m->sh_pl;
     if (window == 0) {
         // one workgroup per region, two workgroups per CU: every window's launch fills the chip once
-        m->sh_rw = (uint32_t)std::min<uint64_t>((uint64_t)m->cus * 2, (uint64_t)PART_MAX_PIECES * 8 / nwindows);
+        m->sh_rw = (uint32_t)std::min<uint64_t>((uint64_t)m->cus * 2, (uint64_t)PART_MAX_PIECES * level2_cpr(m) / nwindows);
         m->sh_windows = nwindows;
         const int g1 = (int)(m->sh_rw * nwindows);
         const uint64_t maxrec = std::max<uint64_t>(est_total_keys, n_keys) + 65536;
@@ -1459,7 +1511,7 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     if (slot == 0) {
         // lists per slot: two workgroups per CU while the pieces of a bucket stay within what a level-2 workgroup walks
         uint32_t gw = (uint32_t)m->cus * 2;
-        while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * 8) gw /= 2;
+        while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * level2_cpr(m)) gw /= 2;
         m->sh_rw = gw;
         m->sh_windows = nslots;
         const int g1 = (int)(gw * nslots);
@@ -1495,11 +1547,18 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     TableParams pp = m->p;
     pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
     const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);
-    hipLaunchKernelGGL(walk_part_kernel, dim3(gw), dim3(SP_NT), lds, st, pp, (const uint4 *)dev_desc, chunk,
-                       (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
-                       (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
-                       m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
-                       (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0, flush_q);
+    if (lds > ((size_t)80 << 10))   // 512 lists: one workgroup per CU, 1024 threads
+        hipLaunchKernelGGL(walk_part_kernel<1024>, dim3(gw), dim3(1024), lds, st, pp, (const uint4 *)dev_desc, chunk,
+                           (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                           (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
+                           m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
+                           (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0, flush_q);
+    else
+        hipLaunchKernelGGL(walk_part_kernel<SP_NT>, dim3(gw), dim3(SP_NT), lds, st, pp, (const uint4 *)dev_desc, chunk,
+                           (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
+                           (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
+                           m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
+                           (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0, flush_q);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
@@ -1518,7 +1577,7 @@ extern "C" int tsx_hip_shard_filter_device(tsx_hip_map *m, const void *dev_desc,
     PartPlan &pl = *m->sh_pl;
     if (slot == 0) {
         uint32_t gw = (uint32_t)m->cus * 2;
-        while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * 8) gw /= 2;
+        while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * level2_cpr(m)) gw /= 2;
         m->sh_rw = gw;
         m->sh_windows = nslots;
         const int g1 = (int)(gw * nslots);
@@ -1665,11 +1724,89 @@ extern "C" int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count
     return TSX_HIP_OK;
 }
 
+// ---- tables above 2^32 slots (l - S > 18): built slab by slab ----------------------------------------------------------
+// 1. every window of the text is DESCRIBED once (line pass + strip_desc_kernel, long descriptions: 32 bytes per 64 start
+//    positions), the descriptions of all windows stay in HBM;
+// 2. for every slab: the owner-filtered walk over every window's descriptions keeps the slab's keys and partitions them by
+//    radix level 1 (one set of sub-lists per window), then ONE level 2 + build for the slab -- a slab is to this loop what a
+//    shard is to a GPU of a multi-GPU run, and the per-slab view of the table parameters is a shard's view (l = slab bits,
+//    shard = slab number) with the table pointers moved to the slab and pos_base = its first slot.
+// The text is walked slab_count times (rolling work only, ~2 ms per 1e9 positions); every key makes its two trips once.
+static const size_t DEV_WINDOW_DEFAULT = (size_t)4 << 30;
+static size_t dev_window_bytes() {
+    size_t w = DEV_WINDOW_DEFAULT;
+    if (const char *e = getenv("TSX_HIP_DEV_WINDOW")) {  // tests exercise the window seams
+        const long long v = atoll(e);
+        if (v >= 4096) w = ((size_t)v + 15) & ~(size_t)15;
+    }
+    return w;
+}
+
+static int count_slabs(tsx_hip_map *m, const uint8_t *base, size_t n, hipStream_t st) {
+    const int sb = slab_bits(m);
+    const uint32_t nslab = 1u << sb;
+    const size_t halo = (size_t)m->p.k - 1, WIN = dev_window_bytes();
+    const uint32_t nwin = (uint32_t)std::max<size_t>(1, (n + WIN - 1) / WIN);
+    // descriptions of all windows, back to back (window w at word offset doff[w] of 32-byte descriptions)
+    std::vector<size_t> doff(nwin + 1, 0);
+    for (uint32_t w = 0; w < nwin; ++w) doff[w + 1] = doff[w] + std::min(WIN, n - (size_t)w * WIN) / 64 + 4096;
+    // (scratch of the map, grown on demand: allocating and freeing gigabytes per call costs more than the kernels)
+    int rc = grow(st, m->d_slabdesc, m->slabdesc_bytes, doff[nwin] * 32 + (size_t)(nwin + 1) * 8);
+    if (rc != TSX_HIP_OK) return rc;
+    uint4 *d_desc = reinterpret_cast<uint4 *>(m->d_slabdesc);
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(m->d_slabdesc + doff[nwin] * 32);
+    auto done = [&](int code) { m->ev_open.clear(); return code; };
+    if (hipMemsetAsync(d_cnt, 0, (size_t)(nwin + 1) * 8, st) != hipSuccess) return done(TSX_HIP_EHIP);
+    for (uint32_t w = 0; w < nwin && rc == TSX_HIP_OK; ++w) {
+        const size_t off = (size_t)w * WIN, own = std::min(WIN, n - off), len = std::min(own + halo, n - off);
+        DescOut dsc;
+        dsc.out = d_desc + doff[w] * 2; dsc.cap = doff[w + 1] - doff[w]; dsc.count = d_cnt + w; dsc.sum = d_cnt + nwin; dsc.long_desc = 1;
+        rc = run_fastq_piece(m, base + off, len, own, off > 0 ? -1 : 0, st, ShardOut(), HotOut(), dsc);
+    }
+    if (rc != TSX_HIP_OK) return done(rc);
+    std::vector<unsigned long long> cnt(nwin + 1);
+    if (hipMemcpyAsync(cnt.data(), d_cnt, (size_t)(nwin + 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return done(TSX_HIP_EHIP);
+    m->ev_open.clear();   // (the description calls queued timing tuples for a sharded build that never comes)
+    const uint64_t kmers = cnt[nwin];
+    if (kmers == 0) return done(TSX_HIP_OK);
+    const TableParams whole = m->p;
+    const bool fresh = m->fresh;
+    const size_t est = (size_t)(kmers / nslab + kmers / nslab / 8) + 65536;
+    for (uint32_t s = 0; s < nslab && rc == TSX_HIP_OK; ++s) {
+        TableParams &v = m->p;     // the slab's view
+        v = whole;
+        v.l = whole.l - sb;
+        v.slot_mask = (1ULL << v.l) - 1ULL;
+        v.shard = s;
+        v.pos_base = (uint64_t)s << v.l;
+        v.table = whole.table + ((uint64_t)s << v.l);
+        v.seg_dirty = whole.seg_dirty + ((uint64_t)s << (v.l - v.S));
+        m->fresh = fresh;
+        hipEvent_t *ev = nullptr;
+        if (m->timing) {
+            if (m->ev_used + EV_N > m->ev.size())
+                for (int i = 0; i < EV_N; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { rc = TSX_HIP_EHIP; break; } m->ev.push_back(e); }
+            if (rc != TSX_HIP_OK) break;
+            ev = &m->ev[m->ev_used]; m->ev_used += EV_N;
+            for (int i = 0; i < 4; ++i) if (hipEventRecord(ev[i], st) != hipSuccess) rc = TSX_HIP_EHIP;
+        }
+        for (uint32_t w = 0; w < nwin && rc == TSX_HIP_OK; ++w)
+            rc = tsx_hip_shard_walk_device(m, d_desc + doff[w] * 2, (size_t)cnt[w], 1, w, nwin, est, nullptr, st);
+        if (rc == TSX_HIP_OK) {
+            if (!m->sh_pl || !m->sh_pl->fused) rc = TSX_HIP_EINVAL;
+            else rc = run_partition_build(m, *m->sh_pl, nullptr, nullptr, 0, st, ev);
+        }
+        if (rc == TSX_HIP_OK && ev && hipEventRecord(ev[7], st) != hipSuccess) rc = TSX_HIP_EHIP;
+    }
+    m->p = whole;
+    if (rc == TSX_HIP_OK) m->fresh = false;
+    return done(rc);
+}
+
 // Device texts are processed in windows so that the partition scratch (about
 // 10 bytes per text byte) stays bounded; windows overlap by the k-1 byte halo
 // exactly like the host pieces.
-static const size_t DEV_WINDOW_DEFAULT = (size_t)4 << 30;
-
 extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, size_t n, void *stream) {
     if (!m || (!dev_text && n) || ((uintptr_t)dev_text & 15)) return TSX_HIP_EINVAL;
     if (m->p.lg != m->p.l) return TSX_HIP_EINVAL;   // a shard: keys of other owners must travel (shard_scan / shard_build)
@@ -1678,11 +1815,8 @@ extern "C" int tsx_hip_count_fastq_device(tsx_hip_map *m, const void *dev_text, 
     HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
     const uint8_t *base = (const uint8_t *)dev_text;
     const size_t halo = (size_t)m->p.k - 1;
-    size_t DEV_WINDOW = DEV_WINDOW_DEFAULT;
-    if (const char *e = getenv("TSX_HIP_DEV_WINDOW")) {  // tests exercise the window seams
-        const long long v = atoll(e);
-        if (v >= 4096) DEV_WINDOW = ((size_t)v + 15) & ~(size_t)15;
-    }
+    const size_t DEV_WINDOW = dev_window_bytes();
+    if (slab_bits(m) && (m->path == 2 || (m->path == 0 && n * 32 >= m->lay.table_bytes))) return count_slabs(m, base, n, st);
     for (size_t off = 0; off < n || off == 0; off += DEV_WINDOW) {
         const size_t own = std::min(DEV_WINDOW, n - off);
         const size_t len = std::min(own + halo, n - off);
@@ -1961,6 +2095,18 @@ extern "C" int tsx_hip_count_fastq_host(tsx_hip_map *m, const char *text, size_t
     if (m->p.lg != m->p.l) return TSX_HIP_EINVAL;   // see tsx_hip_count_fastq_device
     HIP_TRY(hipSetDevice(m->device));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    if (slab_bits(m) && (m->path == 2 || (m->path == 0 && n * 32 >= m->lay.table_bytes))) {
+        // a table built slab by slab walks the whole text once per slab: the text goes to the device in one piece
+        uint8_t *d_text = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_text, n + 256));
+        int rcb = TSX_HIP_OK;
+        if (hipMemcpy(d_text, text, n, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_text + n, '\n', 256) != hipSuccess) rcb = TSX_HIP_EHIP;
+        if (rcb == TSX_HIP_OK) rcb = tsx_hip_count_fastq_device(m, d_text, n, nullptr);
+        if (rcb == TSX_HIP_OK) rcb = tsx_hip_sync(m);
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipFree(d_text);
+        return rcb;
+    }
     int rc = ensure_staging(m, n);
     if (rc != TSX_HIP_OK) return rc;
     hipStream_t st = m->stream;
