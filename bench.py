@@ -106,6 +106,35 @@ def run_check(args, m, T, TD, dist, torch, dist_on, sharded, world, rank, red, d
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t.item())
 
+    if args.workload == "zipf":
+        # everything the table must hold follows from the generator (tsxcount_amd.synth.ZipfExpect): the number of
+        # occurrences and of DISTINCT k-mers, the count of every k-mer of a sample of reads and of the hottest k-mer
+        from tsxcount_amd import synth
+        ex = synth.ZipfExpect(args.seed, args.reads, args.zipf_read_len, synth.zipf_thresholds(args.zipf_templates, args.zipf_a), args.k)
+        detail["totals"] = {"kmers_in_reads": ex.total, "scanned": st["kmers_added"], "sum_of_counts_in_table": st["count_sum"],
+                            "distinct_expected": ex.distinct, "distinct_in_table": st["distinct"]}
+        ok = ok and st["kmers_added"] == ex.total == st["count_sum"] and st["distinct"] == ex.distinct
+        ids = verify.sample_read_ids(0, args.reads, args.check_reads)
+        seqs, cnt = ex.sample(ids)
+        got = m.getKmerCounts(T.encode_many(seqs, args.k))
+        detail["sample"] = {"reads": int(len(ids)), "looked_up": int(len(seqs)), "unequal": int((got != cnt).sum()),
+                            "largest_expected_count": int(cnt.max())}
+        ok = ok and len(seqs) > 0 and detail["sample"]["unequal"] == 0
+        t, p, c = ex.hottest()
+        hot = int(m.getKmerCounts(T.encode_many([synth.zipf_template(args.seed, t, p, args.k)], args.k))[0])
+        detail["hottest_kmer"] = {"expected": c, "table": hot}
+        ok = ok and hot == c
+        import ctypes
+        dbg8 = (ctypes.c_uint64 * 8)()
+        m._lib.tsx_hip_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        m._lib.tsx_hip_debug_counters(m.handle, dbg8)
+        detail["skew"] = {"records_off_the_fast_route": st["fallback_inserts"], "deferred_list_entries": int(dbg8[7]),
+                          "overflow_carries": st["overflow_carries"]}
+        if not args.no_cross_check and m.layout.table_bytes <= (32 << 30):
+            other = "partitioned" if args.path == "atomic" else "atomic"
+            detail["cross"] = verify.cross_check(m, text.data_ptr(), nbytes, other, device=local_rank)
+            ok = ok and detail["cross"]["ok"]
+        return ok, detail
     # totals: every k-mer of the reads was scanned, and the counts held by the table(s) add up to them
     scanned = allsum(st["kmers_added"]) if (world == 1 or sharded) else None
     count_sum = allsum(st["count_sum"])
@@ -197,6 +226,12 @@ def main():
     ap.add_argument("--check-reads", type=int, default=1000, help="reads whose k-mers the check looks up one by one")
     ap.add_argument("--no-cross-check", action="store_true",
                     help="skip the second table (other insert path) of the check")
+    ap.add_argument("--workload", default="reads", choices=["reads", "zipf"],
+                    help="reads: generateFakeSequences.py shape (the BASELINE metric); zipf: BASELINE config 4 -- windows of "
+                         "Zipf(1.2)-picked template sequences (one GPU; give --k 63)")
+    ap.add_argument("--zipf-read-len", type=int, default=250)
+    ap.add_argument("--zipf-templates", type=int, default=1 << 20)
+    ap.add_argument("--zipf-a", type=float, default=1.2)
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded table, collectives) even at world size 1: "
                          "the only way to push the RCCL leg through its API on a 1-GPU box")
@@ -258,10 +293,23 @@ def main():
 
     # synthetic input straight into HBM; every rank owns its own read shard
     first = rank * args.reads
-    nbytes, kmers_rank, _ = T.synth_sizes(args.seed, first, args.reads, args.k)
-    text = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize(dev)
-    T.synth_fastq_device(args.seed, first, args.reads, args.k, text.data_ptr(), nbytes, device=local_rank)
+    zipf = args.workload == "zipf"
+    if zipf:
+        if dist_on:
+            raise SystemExit("bench.py: --workload zipf is a one-GPU configuration (BASELINE config 4)")
+        from tsxcount_amd import synth
+        zthr = synth.zipf_thresholds(args.zipf_templates, args.zipf_a)
+        nbytes = T.synth_zipf_device(args.seed, args.reads, args.zipf_read_len, zthr)
+        kmers_rank = args.reads * max(0, args.zipf_read_len - args.k + 1)
+        text = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        text[nbytes:] = 10
+        torch.cuda.synchronize(dev)
+        T.synth_zipf_device(args.seed, args.reads, args.zipf_read_len, zthr, text.data_ptr(), nbytes, device=local_rank)
+    else:
+        nbytes, kmers_rank, _ = T.synth_sizes(args.seed, first, args.reads, args.k)
+        text = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        T.synth_fastq_device(args.seed, first, args.reads, args.k, text.data_ptr(), nbytes, device=local_rank)
 
     # N > 1: ONE table sharded by slot range over the GPUs (2^(l + log2 N) slots in all, so the
     # load factor per GPU is the same at every N: weak scaling).  Keys travel to their owner
@@ -385,12 +433,15 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "k-mers/sec inserted, k=%d, 1e9 synthetic k-mers, 1/2/4/8 GPU; --check pass" % args.k,
+            "metric": ("k-mers/sec inserted, k=%d, Zipf-skewed synthetic reads, 1 GPU; --check pass" % args.k) if zipf else
+                      "k-mers/sec inserted, k=%d, 1e9 synthetic k-mers, 1/2/4/8 GPU; --check pass" % args.k,
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "rccl_ranks": (dist.get_world_size() if dist_on else 0), "backend": (dist.get_backend() if dist_on else None),
-            "config": {"workload": "synthetic FASTQ (generateFakeSequences.py shape), %d reads/GPU = %d k-mers/GPU, "
+            "config": {"workload": ("Zipf(%.2f) windows of %d bases over %d templates (BASELINE config 4), "
+                                    % (args.zipf_a, args.zipf_read_len, args.zipf_templates) if zipf else
+                                    "synthetic FASTQ (generateFakeSequences.py shape), ") + "%d reads/GPU = %d k-mers/GPU, "
                                    "k=%d, table 2^%d slots/GPU, %s insert path%s%s"
                                    % (args.reads, kmers_rank, args.k, args.l,
                                       "partitioned" if partitioned else "atomic",

@@ -359,6 +359,16 @@ int tsx_hip_synth_fastq_device(uint64_t seed, uint64_t first_read, uint64_t n_re
                                void *dev_out, size_t cap, uint64_t *bytes_out, uint64_t *kmers_out,
                                uint64_t *polya_kmers_out, int device, void *stream);
 
+/*
+ * Zipf-skewed synthetic reads (BASELINE config 4: contention / reprobe stress): n_templates random template sequences of
+ * 2 * read_len bases, read r = a window of read_len bases of template pick_r, pick_r Zipf distributed: thr (host,
+ * n_templates ascending uint64) are the upper ends of the templates' shares of [0, 2^64).  '@z<r>' headers, 'I'
+ * qualities.  Sizing call: dev_out == NULL.  tsxcount_amd/synth.py: zipf_thresholds(), the numpy twin and the analytic
+ * count of every k-mer (what the bench's check compares the table with).
+ */
+int tsx_hip_synth_zipf_device(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint32_t n_templates, const uint64_t *thr,
+                              void *dev_out, size_t cap, uint64_t *bytes_out, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1094,3 +1094,39 @@ def test_radix_levels_of_512_lists(T, monkeypatch, l, k):
         assert st["kmers_added"] == rep * n and st["distinct"] == len(kmers) and st["insert_failures"] == 0
         assert np.array_equal(m.getKmerCounts(kmers), rep * counts)
     m.close()
+
+
+@pytest.mark.parametrize("k,path", [(63, "partitioned"), (63, "atomic"), (31, "partitioned")])
+def test_zipf_device_generator_and_analytic_counts(T, k, path):
+    """BASELINE config 4's input at test size: the device generator writes the text of tsxcount_amd.synth.zipf_text byte
+    for byte, and the table holds, for every k-mer, the count synth.ZipfExpect derives from the generator alone (reads of
+    the k-mer's template whose window covers it) -- the hottest k-mer occurs in a third of all reads.  ZipfExpect itself
+    is held to a dictionary count on the CPU."""
+    import torch
+    from tsxcount_amd import synth
+    seed, n_reads, rl, nt = 13, 6000, 150, 300
+    thr = synth.zipf_thresholds(nt, 1.2)
+    nb = T.synth_zipf_device(seed, n_reads, rl, thr)
+    buf = torch.empty(nb + 256, dtype=torch.uint8, device="cuda:0")
+    buf[nb:] = 10
+    torch.cuda.synchronize()
+    assert T.synth_zipf_device(seed, n_reads, rl, thr, buf.data_ptr(), nb) == nb
+    text = bytes(buf[:nb].cpu().numpy())
+    assert text == synth.zipf_text(seed, n_reads, rl, thr)
+    ex = synth.ZipfExpect(seed, n_reads, rl, thr, k)
+    ref = python_counts(text, k)
+    assert ex.total == sum(ref.values()) and ex.distinct == len(ref)
+    m = T.TSXHashMapHIP(22, 0, k)
+    m.set_path(path)
+    m.countFastqDevice(buf.data_ptr(), nb)
+    m.sync()
+    st = m.stats()
+    assert st["kmers_added"] == ex.total and st["distinct"] == ex.distinct and st["count_sum"] == ex.total
+    assert st["insert_failures"] == 0 and st["overflow_failures"] == 0
+    seqs, cnt = ex.sample(range(0, n_reads, 40))
+    assert np.array_equal(m.getKmerCounts(T.encode_many(seqs, k)), cnt)
+    assert all(ref[sq] == int(c) for sq, c in zip(seqs, cnt))
+    t, p, c = ex.hottest()
+    hot = synth.zipf_template(seed, t, p, k)
+    assert c > n_reads // 8 and int(m.getKmerCounts(T.encode_many([hot], k))[0]) == c == ref[hot]
+    m.close()

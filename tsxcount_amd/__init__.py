@@ -119,6 +119,7 @@ def lib():
     L.tsx_hip_set_path.argtypes = [vp, ci]
     L.tsx_hip_set_record_lines.argtypes = [vp, ci]
     L.tsx_hip_synth_fastq_device.argtypes = [u64, u64, u64, ci, vp, sz, u64p, u64p, u64p, ci, vp]
+    L.tsx_hip_synth_zipf_device.argtypes = [u64, u64, ctypes.c_uint32, ctypes.c_uint32, u64p, vp, sz, u64p, ci, vp]
     L.tsx_hip_group_create.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(ci), ci, ci, ci, ci, u64, ci]
     L.tsx_hip_group_destroy.argtypes = [vp]
     L.tsx_hip_group_destroy.restype = None
@@ -492,3 +493,13 @@ def synth_fastq_device(seed, first_read, n_reads, k, dev_ptr, cap, device=0, str
                                             ctypes.byref(nb), ctypes.byref(nk), None, device,
                                             ctypes.c_void_p(stream) if stream else None))
     return int(nb.value), int(nk.value)
+
+
+def synth_zipf_device(seed, n_reads, read_len, thr, dev_ptr=None, cap=0, device=0, stream=None):
+    """Zipf-skewed reads straight into device memory (tsx_hip_synth_zipf_device; thr from synth.zipf_thresholds).
+    Returns the byte count; dev_ptr None = sizing call."""
+    thr = np.ascontiguousarray(thr, dtype=np.uint64)
+    nb = ctypes.c_uint64(0)
+    _check(lib().tsx_hip_synth_zipf_device(seed, n_reads, read_len, len(thr), _p(thr), ctypes.c_void_p(dev_ptr) if dev_ptr else None,
+                                           cap, ctypes.byref(nb), device, ctypes.c_void_p(stream) if stream else None))
+    return int(nb.value)

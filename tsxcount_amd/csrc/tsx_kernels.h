@@ -1690,4 +1690,42 @@ __global__ __launch_bounds__(NT) void synth_fill_kernel(uint64_t seed, uint64_t 
     }
 }
 
+// Zipf-skewed reads (BASELINE config 4): n_templates random template sequences of 2 * read_len bases, read r is the
+// window [start_r, start_r + read_len) of template pick_r, pick_r drawn with Zipf rank weights: thr[t] = the upper end of
+// template t's share of [0, 2^64) (thr is ascending, the last entry 2^64 - 1), pick_r = number of thr entries < u_r for
+// u_r = synth_mix(seed, r, 0).  Record: "@z<r>\n" bases "\n+\n" 'I' * read_len "\n".  tsxcount_amd/synth.py has the numpy twin.
+__device__ __host__ inline uint32_t zipf_pick(const uint64_t *thr, uint32_t n_templates, uint64_t u) {
+    uint32_t lo = 0, hi = n_templates - 1;   // first t with thr[t] >= u
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (thr[mid] >= u) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(NT) void synth_zipf_kernel(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint32_t n_templates,
+                                                        const uint64_t *thr, const uint64_t *offsets, uint8_t *out) {
+    for (uint64_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint32_t t = zipf_pick(thr, n_templates, synth_mix(seed, r, 0));
+        const uint32_t start = (uint32_t)(synth_mix(seed, r, 1) % (uint64_t)(read_len + 1));
+        uint8_t *o = out + offsets[r];
+        char digits[24]; int nd = 0; uint64_t v = r;
+        do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+        const uint32_t hl = 2u + (uint32_t)nd + 1u;
+        if (threadIdx.x == 0) {
+            o[0] = '@'; o[1] = 'z';
+            for (int d = 0; d < nd; ++d) o[2 + d] = (uint8_t)digits[nd - 1 - d];
+            o[2 + nd] = '\n';
+        }
+        uint8_t *seq = o + hl;
+        const uint64_t tid64 = 0x5A495046ULL + (uint64_t)t;   // template t draws its bases from a stream of its own
+        for (uint32_t j = threadIdx.x; j < read_len; j += NT) {
+            const uint32_t q = start + j;
+            const uint64_t w = synth_mix(seed ^ 0x7E3779B97F4A7C15ULL, tid64, 2 + (q >> 5));
+            seq[j] = (uint8_t)"ACGT"[(w >> (2 * (q & 31))) & 3];
+            seq[read_len + 3 + j] = 'I';
+        }
+        if (threadIdx.x == 0) { seq[read_len] = '\n'; seq[read_len + 1] = '+'; seq[read_len + 2] = '\n'; seq[2 * read_len + 3] = '\n'; }
+    }
+}
+
 }  // namespace tsx

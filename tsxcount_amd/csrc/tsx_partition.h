@@ -21,6 +21,7 @@
 // build has written its segments, so a freshly cleared table needs no memset.
 #pragma once
 #include "tsx_kernels.h"
+#include <type_traits>
 
 namespace tsx {
 
@@ -89,17 +90,159 @@ __device__ __forceinline__ uint64_t format_record(const TableParams &p, uint64_t
 
 constexpr int PART_MAX_PIECES = 512;   // pieces of a source region one workgroup may have to walk (src_np / cpr)
 constexpr int PART_ITER = 3;  // flush jobs an octet serves per pass (128 jobs per pass: a usual round of 256 lists)
+// ---- records that find their list full (partition_ring_kernel) --------------------------------------------------------
+// What does not fit a destination list: almost always hot keys.  Three stations, all of one workgroup:
+//   cache   OVF_N (key -> count) places in LDS, four per key; a key is ADMITTED only when it comes as a combined record
+//           (d >= 2: the wave has just seen it more than once) -- once a hot key's list is full the cold keys of its
+//           segment spill as well, one each, and would take every place before the hot keys get there;
+//   queue   the workgroup's overflow queue in HBM (ovq_cap single records), inserted after the build;
+//   chunks  the deferred list, in chunks of dch records that belong to this workgroup alone: one global atomic per
+//           chunk, an LDS counter per record (skewed input -- BASELINE config 4 -- spills 4.6e8 records; one atomic each
+//           on the list's single counter took 1.8 s).  deferred_insert_kernel finds a bucket's records side by side.
+// Only the SKEW form of the kernel holds this code (see there).  The state is one LDS struct of the kernel.
+template <int RW> struct SpillState {
+    static constexpr uint32_t DCH_MAX = (RW == 4) ? 48 : 96;   // (LDS: two workgroups of 80 KB share a CU)
+    uint64_t ovk[OVF_N * RW];               // cached keys (word 0 xor OVF_SALT, 0 = free)
+    unsigned long long dch[DCH_MAX];        // first record of chunk ci, + 1 (0: not allocated yet)
+    uint32_t ovc[OVF_N];                    // their counts
+    uint32_t ovr[OVF_N];                    // RW > 1: the other words of the cached key have been written
+    uint32_t ovn;                           // records in the overflow queue
+    uint32_t dn;                            // records deferred in chunks
+    uint32_t skew;                          // a record of this workgroup has found its list full
+};
+#define TSX_LDS __attribute__((address_space(3)))
+template <int RW>
+__device__ __forceinline__ void spill_record(const TableParams *pk, TSX_LDS SpillState<RW> *sp, uint64_t *ovq, uint32_t ovq_cap,
+                                             uint32_t dch, RecVal<RW> r, uint32_t d) {
+    sp->skew = 1u;
+    const uint64_t kk = r.w[0] ^ OVF_SALT;
+    if (kk != 0) {
+        uint64_t mixin = r.w[0];
+#pragma unroll
+        for (int t = 1; t < RW; ++t) mixin ^= r.w[t] * 0x9E3779B97F4A7C15ULL;
+        uint32_t slot = (uint32_t)(mix64(mixin) >> 40) & (OVF_N - 1);
+        for (int pr = 0; pr < 4; ++pr, slot = (slot + 1) & (OVF_N - 1)) {
+            TSX_LDS unsigned long long *w0 = (TSX_LDS unsigned long long *)&sp->ovk[slot * RW];
+            unsigned long long old = 0ULL;
+            if (d >= 2u) __hip_atomic_compare_exchange_strong(w0, &old, (unsigned long long)kk, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+            else old = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 0ULL) {
+                if (d < 2u) break;   // not cached, and not to be
+                if constexpr (RW > 1) {   // claimed: publish the other words, then the ready flag
+#pragma unroll
+                    for (int t = 1; t < RW; ++t) sp->ovk[slot * RW + t] = r.w[t];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(&sp->ovr[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __hip_atomic_fetch_add(&sp->ovc[slot], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
+            if (old == kk) {
+                bool same = true;
+                if constexpr (RW > 1) {
+                    same = __hip_atomic_load(&sp->ovr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+                    if (same) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                        for (int t = 1; t < RW; ++t) same &= (sp->ovk[slot * RW + t] == r.w[t]);
+                    }
+                }
+                if (same) { __hip_atomic_fetch_add(&sp->ovc[slot], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+            }
+        }
+    }
+    if (ovq && d == 1u) {
+        const uint32_t at = __hip_atomic_fetch_add(&sp->ovn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (at < ovq_cap) { store_rec<RW>(ovq + (size_t)at * RW, r.w); return; }
+    }
+    if (dch == 0) { defer_append_v<RW>(pk, r, d); return; }
+    const uint32_t at = __hip_atomic_fetch_add(&sp->dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t ci = at / dch, off = at % dch;
+    if (ci >= SpillState<RW>::DCH_MAX) { defer_append_v<RW>(pk, r, d); return; }
+    if (off == 0) {   // the lane that opens a chunk takes it from the list (its store comes BEFORE the wait below,
+                      // also for the other lanes of this wave: no lane waits for a lane that waits)
+        const unsigned long long first = atomicAdd(pk->defer.n, (unsigned long long)dch);
+        __hip_atomic_store(&sp->dch[ci], first + 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    unsigned long long first;
+    do { first = __hip_atomic_load(&sp->dch[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (first == 0ULL);
+    first -= 1ULL;
+    if (first + dch <= pk->defer.cap) {
+        store_rec<RW>(pk->defer.rec + (first + off) * RW, r.w);
+        pk->defer.cnt[first + off] = (unsigned long long)d;
+    } else {
+        atomicAdd(&pk->stats[ST_FAIL], (unsigned long long)d);
+    }
+}
+
+// Which buckets are skewed enough for the SKEW form of level 2?  One workgroup per level-1 bucket looks at SAMPLE records
+// of it (runs of 16 at a pseudo-random place of every piece, or one run of a packed bucket), counts them in an LDS table
+// by a 64-bit tag of the record and sets flag[bucket] when MANY different records show up HOT times or more: more hot keys
+// than the plain form's 64-place cache absorbs.  (A few hot keys per bucket are normal and cost the plain form nothing:
+// the reads of the bench end in poly-A tails, and the 4^j k-mers with j = 1..5 bases in front of 26+ A's occur 10^3-10^5
+// times each -- one or two of them per bucket.)  A miss costs time -- the plain form is correct for any input --, never a count.
+template <int RW>
+__global__ __launch_bounds__(256) void skew_probe_kernel(const uint64_t *src, const unsigned long long *src_start,
+                                                         const unsigned long long *src_cnt, const unsigned long long *src_pcnt,
+                                                         uint32_t src_np, uint64_t src_pcap, uint32_t *flag) {
+    constexpr uint32_t TN = 8192, SAMPLE = 4096, HOT = 4, MANY = 8;
+    __shared__ uint64_t s_tag[TN];
+    __shared__ uint32_t s_num[TN];
+    __shared__ uint32_t s_seen, s_mass;
+    const uint32_t tid = threadIdx.x, r = blockIdx.x;
+    for (uint32_t t = tid; t < TN; t += 256) { s_tag[t] = 0; s_num[t] = 0; }
+    if (tid == 0) { s_seen = 0; s_mass = 0; }
+    __syncthreads();
+    uint32_t seen = 0;
+    for (uint32_t i = tid; i < SAMPLE; i += 256) {
+        uint64_t at = ~0ULL;   // record index in src
+        if (src_pcnt) {        // run i / 16 of the sample comes from piece (i / 16) * src_np / (SAMPLE / 16)
+            const uint32_t run = i >> 4, g = (uint32_t)(((uint64_t)run * src_np) / (SAMPLE / 16));
+            const uint64_t pa = (uint64_t)r * src_np + g, cnt = min((uint64_t)src_pcnt[pa], src_pcap);
+            if (cnt >= 16) at = pa * src_pcap + (mix64(pa + 0x51ED) % (cnt - 15)) + (i & 15u);
+        } else {
+            const uint64_t cnt = src_cnt[r];
+            if (cnt > i) at = (uint64_t)src_start[r] + (cnt > SAMPLE ? (mix64(r + 0x51ED) % (cnt - SAMPLE + 1)) : 0) + i;
+        }
+        if (at == ~0ULL) continue;
+        ++seen;
+        uint64_t tag = 0;
+#pragma unroll
+        for (int t = 0; t < RW; ++t) tag ^= mix64(src[at * RW + t] + (uint64_t)t);
+        tag |= 1ULL;
+        uint32_t slot = (uint32_t)(tag >> 40) & (TN - 1);
+        for (int pr = 0; pr < 8; ++pr, slot = (slot + 1) & (TN - 1)) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_tag[slot]), 0ULL, (unsigned long long)tag);
+            if (old == 0ULL || old == tag) { atomicAdd(&s_num[slot], 1u); break; }
+        }
+    }
+    atomicAdd(&s_seen, seen);
+    __syncthreads();
+    uint32_t hot = 0;
+    for (uint32_t t = tid; t < TN; t += 256) if (s_num[t] >= HOT) ++hot;
+    if (hot) atomicAdd(&s_mass, hot);
+    __syncthreads();
+    if (tid == 0) flag[r] = (s_mass >= MANY && s_seen >= 256u) ? 1u : 0u;
+}
+
 // NT threads: 512 where two workgroups share a CU (<= 80 KB of rings: up to 256 lists); 1024 where the rings of 512 lists
 // leave room for one workgroup only -- 16 waves per CU either way (8 waves: level 2 of a 2^18-segment table 7.5 ms per
 // 1e9 keys instead of 3.1).
-template <int RW, int NT = RING_NT>
+// SKEW: the kernel exists in two forms that are BOTH launched for level 2; *skew_flag (set by skew_probe_kernel from a
+// sample of every bucket) says which of them works, the other returns at once.  The plain form is round 2's kernel: what
+// does not fit a list goes through a one-place cache, the overflow queue and the deferred list's single counter -- fine
+// for the odd hot key, and nothing of the skew machinery costs it an instruction (all of it inlined into one kernel made
+// level 2 of uniform input 0.5 ms slower: code size; as a function call: 0.9 ms, the calls constrain the hot loop's
+// registers).  The skew form: spill_record, combined records, lists looked at before their rings.
+template <int RW, int NT = RING_NT, bool SKEW = false>
 __global__ __launch_bounds__(NT) void partition_ring_kernel(
     TableParams p, const uint64_t *src, const unsigned long long *src_start, const unsigned long long *src_cnt,
     uint64_t src_cap, uint32_t nregions, uint32_t cpr, uint64_t *dst, const unsigned long long *offs,
     const unsigned long long *offs_base, unsigned long long *dst_cnt, uint64_t dst_cap, uint32_t nb, uint32_t shift,
     uint32_t capbits, int dbg, uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap,
     const unsigned long long *src_pcnt, uint32_t src_np, uint64_t src_pcap, int dst_bm, unsigned long long *key_sum,
-    uint32_t dst_r0, uint32_t dst_nr, int fmt) {
+    uint32_t dst_r0, uint32_t dst_nr, int fmt, uint32_t dch, const uint32_t *skew_flag) {
     constexpr int RPT = (PART_WPT >= RW) ? PART_WPT / RW : 1;   // records per thread per batch
     extern __shared__ uint64_t s_part[];  // rings | cursors | limits | flush descriptors | tails | heads | jobs
     const uint32_t CAP = 1u << capbits, cmask = CAP - 1;
@@ -111,16 +254,15 @@ __global__ __launch_bounds__(NT) void partition_ring_kernel(
     uint32_t *s_head = s_tail + nb;
     uint32_t *s_job = s_head + nb;      // lists with something to flush this round, in arrival order
     __shared__ uint32_t s_njobs[2];     // their number; two counters used alternately (reset one round ahead)
-    __shared__ uint32_t s_ovn;          // records in this workgroup's overflow queue
-    __shared__ uint64_t s_ovk[OVF_N * RW];   // spilled hot keys (word 0 xor OVF_SALT, 0 = free) and their counts
-    __shared__ uint32_t s_ovc[OVF_N];
-    __shared__ uint32_t s_ovr[OVF_N];   // RW > 1: the other words of the cached key have been written
+    __shared__ SpillState<RW> s_sp;     // records that find their list full: see spill_record
     const uint32_t tid = threadIdx.x;
     const uint32_t r = blockIdx.x / cpr, c = blockIdx.x % cpr;
     if (r >= nregions) return;
-    if (tid < OVF_N) { s_ovk[tid * RW] = 0; s_ovc[tid] = 0; s_ovr[tid] = 0; }
+    if (skew_flag && (skew_flag[r] != 0u) != SKEW) return;   // the other form of this kernel works on this bucket
+    if (tid < OVF_N) { s_sp.ovk[tid * RW] = 0; s_sp.ovc[tid] = 0; s_sp.ovr[tid] = 0; }
     if (tid < 2) s_njobs[tid] = 0;
-    if (tid == 0) s_ovn = 0;
+    if (tid == 0) { s_sp.ovn = 0; s_sp.dn = 0; s_sp.skew = 0; }
+    if (tid < SpillState<RW>::DCH_MAX) s_sp.dch[tid] = 0;
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap * RW : nullptr;
     for (uint32_t b = tid; b < nb; b += NT) {
         s_tail[b] = 0; s_head[b] = 0;
@@ -147,41 +289,49 @@ __global__ __launch_bounds__(NT) void partition_ring_kernel(
     uint32_t spilled = 0;  // per thread; one atomic per wave at the end
     // A record that found its list full.  In line: one probe of the spill cache (a cached hot key hits it)
     // and the overflow queue (an ordinary record misses); the deferred list takes what the queue cannot.
-    auto spill = [&](const uint64_t (&rec)[RW]) {
-        ++spilled;
-        const uint64_t kk = rec[0] ^ OVF_SALT;
-        if (kk != 0) {
-            uint64_t mixin = rec[0];
+    // (d: the occurrences the record stands for: 1, or the equal records a wave sends away together)
+    auto spill = [&](const uint64_t (&rec)[RW], uint32_t d = 1u) {
+        spilled += d;
+        if constexpr (SKEW) {
+            RecVal<RW> v;
 #pragma unroll
-            for (int t = 1; t < RW; ++t) mixin ^= rec[t];
-            const uint32_t slot = (uint32_t)(mix64(mixin) >> 40) & (OVF_N - 1);
-            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot * RW]), 0ULL,
-                                                     (unsigned long long)kk);
-            if constexpr (RW == 1) {
-                if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
-            } else {
-                if (old == 0ULL) {   // claimed: publish the other words, then the ready flag
+            for (int t = 0; t < RW; ++t) v.w[t] = rec[t];
+            spill_record<RW>(pk, (TSX_LDS SpillState<RW> *)&s_sp, ovq, ovq_cap, dch, v, d);
+        } else {   // one probe of the cache (a cached hot key hits it), the overflow queue, the deferred list
+            const uint64_t kk = rec[0] ^ OVF_SALT;
+            if (kk != 0) {
+                uint64_t mixin = rec[0];
 #pragma unroll
-                    for (int t = 1; t < RW; ++t) s_ovk[slot * RW + t] = rec[t];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __hip_atomic_store(&s_ovr[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    atomicAdd(&s_ovc[slot], 1u);
-                    return;
-                }
-                if (old == kk && __hip_atomic_load(&s_ovr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    bool same = true;
+                for (int t = 1; t < RW; ++t) mixin ^= rec[t];
+                const uint32_t slot = (uint32_t)(mix64(mixin) >> 40) & (OVF_N - 1);
+                const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_sp.ovk[slot * RW]), 0ULL,
+                                                         (unsigned long long)kk);
+                if constexpr (RW == 1) {
+                    if (old == 0ULL || old == kk) { atomicAdd(&s_sp.ovc[slot], 1u); return; }
+                } else {
+                    if (old == 0ULL) {   // claimed: publish the other words, then the ready flag
 #pragma unroll
-                    for (int t = 1; t < RW; ++t) same &= (s_ovk[slot * RW + t] == rec[t]);
-                    if (same) { atomicAdd(&s_ovc[slot], 1u); return; }
+                        for (int t = 1; t < RW; ++t) s_sp.ovk[slot * RW + t] = rec[t];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __hip_atomic_store(&s_sp.ovr[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        atomicAdd(&s_sp.ovc[slot], 1u);
+                        return;
+                    }
+                    if (old == kk && __hip_atomic_load(&s_sp.ovr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        bool same = true;
+#pragma unroll
+                        for (int t = 1; t < RW; ++t) same &= (s_sp.ovk[slot * RW + t] == rec[t]);
+                        if (same) { atomicAdd(&s_sp.ovc[slot], 1u); return; }
+                    }
                 }
             }
+            if (ovq) {
+                const uint32_t at = atomicAdd(&s_sp.ovn, 1u);
+                if (at < ovq_cap) { store_rec<RW>(ovq + (size_t)at * RW, rec); return; }
+            }
+            defer_append<RW>(pk, rec, 1);
         }
-        if (ovq) {
-            const uint32_t at = atomicAdd(&s_ovn, 1u);
-            if (at < ovq_cap) { store_rec<RW>(ovq + (size_t)at * RW, rec); return; }
-        }
-        defer_append<RW>(pk, rec, 1);
     };
     // one word of a burst: word q of the burst that starts at ring index hd of `ring` and at destination `at`
     auto put_word = [&](uint64_t w, const uint64_t *ring, uint32_t hd, uint32_t q, unsigned long long at,
@@ -326,34 +476,70 @@ __global__ __launch_bounds__(NT) void partition_ring_kernel(
         const Batch bn = next_batch();
         load_batch(bn, nxt);
         // all ring places of the batch are taken before any is used: the returning LDS atomics
-        // of a thread are in flight together
-        uint32_t bq[RPT], slot[RPT], head[RPT];
+        // of a thread are in flight together.
+        // Two forms of the append.  The plain one is what uniform input runs.  Once a record of this workgroup has found
+        // its list full (s_skew: skewed input, BASELINE config 4) the batches take the second form: a record first looks
+        // whether ITS list is full and then skips the ring altogether (two same-address LDS atomics and a burst that
+        // would spill anyway), and the wave sends equal homeless records away as ONE entry with their number.
+        auto append = [&](auto skew_tag) {
+            constexpr bool HOT = decltype(skew_tag)::value;   // lists of this workgroup have run full
+            uint32_t bq[RPT], slot[RPT], head[RPT];
+            bool pre_full[RPT];
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const uint32_t j = (uint32_t)q * NT + tid;
-            if (key_sum && j < bc.nvalid) ksum += cur[q][0];
-            bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
-            slot[q] = (j < bc.nvalid) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
-        }
+            for (int q = 0; q < RPT; ++q) {
+                const uint32_t j = (uint32_t)q * NT + tid;
+                if (key_sum && j < bc.nvalid) ksum += cur[q][0];
+                bq[q] = (uint32_t)(cur[q][0] >> shift) & (nb - 1);
+                pre_full[q] = HOT && j < bc.nvalid && s_cur[bq[q]] >= s_lim[bq[q]];
+                slot[q] = (j < bc.nvalid && !pre_full[q]) ? atomicAdd(&s_tail[bq[q]], (uint32_t)RW) : 0u;
+            }
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) head[q] = s_head[bq[q]];
+            for (int q = 0; q < RPT; ++q) head[q] = s_head[bq[q]];
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const uint32_t j = (uint32_t)q * NT + tid;
-            if (j < bc.nvalid) {
-                const uint32_t b = bq[q];
-                if (slot[q] - head[q] < CAP) {   // RW | CAP and records are RW-aligned: a record never wraps
-                    uint64_t *ring = s_stage + ((size_t)b << capbits) + (slot[q] & cmask);
+            for (int q = 0; q < RPT; ++q) {
+                const uint32_t j = (uint32_t)q * NT + tid;
+                bool homeless = pre_full[q];   // ring full AND list full, or the list seen full up front
+                if (j < bc.nvalid && !pre_full[q]) {
+                    const uint32_t b = bq[q];
+                    if (slot[q] - head[q] < CAP) {   // RW | CAP and records are RW-aligned: a record never wraps
+                        uint64_t *ring = s_stage + ((size_t)b << capbits) + (slot[q] & cmask);
 #pragma unroll
-                    for (int t = 0; t < RW; ++t) ring[t] = cur[q][t];
-                } else if (!(dbg & 256)) {  // ring full: take the next place of the list directly
-                    const unsigned long long at = atomicAdd(&s_cur[b], (unsigned long long)RW);
-                    if (at < s_lim[b]) {
-                        if (RW == 1 && fmt) dst[at] = format_record(p, cur[q][0]);
-                        else store_rec<RW>(dst + at, cur[q]);
-                    } else spill(cur[q]);
+                        for (int t = 0; t < RW; ++t) ring[t] = cur[q][t];
+                    } else if (!(dbg & 256)) {  // ring full: take the next place of the list directly
+                        const unsigned long long at = atomicAdd(&s_cur[b], (unsigned long long)RW);
+                        if (at < s_lim[b]) {
+                            if (RW == 1 && fmt) dst[at] = format_record(p, cur[q][0]);
+                            else store_rec<RW>(dst + at, cur[q]);
+                        } else if (HOT) homeless = true;
+                        else spill(cur[q]);
+                    }
+                }
+                if constexpr (HOT) {
+                    // two rounds of: the first homeless lane's record -- who has the same?  What is left goes one by one.
+                    unsigned long long todo = __ballot(homeless);
+                    for (int rnd = 0; rnd < 2 && todo != 0ULL; ++rnd) {
+                        const int L = __builtin_ctzll(todo);
+                        bool same = homeless;
+#pragma unroll
+                        for (int t = 0; t < RW; ++t) {
+                            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)cur[q][t], L),
+                                           hi = __builtin_amdgcn_readlane((uint32_t)(cur[q][t] >> 32), L);
+                            same &= (cur[q][t] == (((uint64_t)hi << 32) | lo));
+                        }
+                        const unsigned long long mm = __ballot(same);
+                        if ((int)(tid & 63u) == L) spill(cur[q], (uint32_t)__builtin_popcountll(mm));
+                        if (same) homeless = false;
+                        todo &= ~mm;
+                    }
+                    if (homeless) spill(cur[q]);
                 }
             }
+        };
+        if constexpr (SKEW) {
+            if (s_sp.skew != 0u) append(std::true_type{});
+            else append(std::false_type{});
+        } else {
+            append(std::false_type{});
         }
         lds_barrier();
         flush(false, [&]() {
@@ -368,19 +554,27 @@ __global__ __launch_bounds__(NT) void partition_ring_kernel(
     }
     flush(true, []() {});
     lds_barrier();
+    {   // the unused tail of this workgroup's last chunk: count 0 = "no record" to deferred_insert_kernel
+        const uint32_t dn = SKEW ? s_sp.dn : 0u;
+        if (dch && dn % dch != 0u && (dn - 1u) / dch < SpillState<RW>::DCH_MAX) {
+            const unsigned long long first = s_sp.dch[(dn - 1u) / dch] - 1ULL;
+            if (first + dch <= pk->defer.cap)
+                for (uint32_t o = dn % dch + tid; o < dch; o += NT) pk->defer.cnt[first + o] = 0ULL;
+        }
+    }
     if (dst_cnt)
         for (uint32_t b = tid; b < nb; b += NT) {
             const uint64_t li = dst_bm ? ((uint64_t)b * dst_nr + dst_r0 + r) * cpr + c : ((uint64_t)r * nb + b) * cpr + c;
             dst_cnt[li] = (min(s_cur[b], s_lim[b]) - li * dst_cap * RW) / RW;
         }
-    if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) {   // hot keys: one deferred entry each, with the total
+    if (tid < OVF_N && s_sp.ovc[tid] && !(dbg & 1)) {   // hot keys: one deferred entry each, with the total
         uint64_t rec[RW];
 #pragma unroll
-        for (int t = 0; t < RW; ++t) rec[t] = s_ovk[tid * RW + t];
+        for (int t = 0; t < RW; ++t) rec[t] = s_sp.ovk[tid * RW + t];
         rec[0] ^= OVF_SALT;
-        defer_append<RW>(pk, rec, s_ovc[tid]);
+        defer_append<RW>(pk, rec, s_sp.ovc[tid]);
     }
-    if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
+    if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_sp.ovn, ovq_cap);
     for (int d = 32; d > 0; d >>= 1) spilled += __shfl_down(spilled, d, 64);
     if ((tid & 63) == 0 && spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
     if (key_sum) {
@@ -1134,52 +1328,69 @@ __global__ __launch_bounds__(PART_NT) void deferred_insert_kernel(TableParams p,
                                                                   uint64_t cap) {
     constexpr int RW = RecWords<WK>::value;
     const uint64_t n = min(n_ptr ? (uint64_t)*n_ptr : n_fixed, cap);
-    if constexpr (WK == 1) {
-        // The list is mostly the same few hot k-mers over and over (every scan wave drains its homopolymer
-        // cache, every level-2 workgroup its spill cache): a workgroup first sums equal keys of its share in
-        // an LDS table, so that a hot key costs one same-address global atomic per WORKGROUP, not per entry.
-        constexpr uint32_t DN = 1024;
-        __shared__ uint64_t s_k[DN];
-        __shared__ unsigned long long s_c[DN];
-        const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
-        const uint64_t lo = min(n, (uint64_t)blockIdx.x * per), hi = min(n, lo + per);
-        for (uint64_t base = lo; base < hi; base += DN / 2) {   // table at most half full
-            for (uint32_t t = threadIdx.x; t < DN; t += PART_NT) { s_k[t] = 0; s_c[t] = 0; }
-            __syncthreads();
-            const uint64_t end = min(hi, base + DN / 2);
-            for (uint64_t i = base + threadIdx.x; i < end; i += PART_NT) {
-                const uint64_t key = rec[i], d = cnt ? cnt[i] : 1ULL;
-                const uint64_t h1[1] = {key};
-                if (d == 0 || (p.lg != p.l && owner_shard<1>(p, h1) != p.shard)) continue;
-                const uint64_t kk = key ^ OVF_SALT;
-                uint32_t slot = (uint32_t)(mix64(key) >> 40) & (DN - 1);
-                bool done = false;
-                for (int pr = 0; pr < 16 && kk != 0 && !done; ++pr) {
-                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_k[slot]), 0ULL,
-                                                             (unsigned long long)kk);
-                    if (old == 0ULL || old == kk) { atomicAdd(&s_c[slot], (unsigned long long)d); done = true; }
-                    slot = (slot + 1) & (DN - 1);
-                }
-                if (!done) insert_key<1>(p, h1, d);
-            }
-            __syncthreads();
-            for (uint32_t t = threadIdx.x; t < DN; t += PART_NT)
-                if (s_c[t]) {
-                    const uint64_t h1[1] = {s_k[t] ^ OVF_SALT};
-                    insert_key<1>(p, h1, s_c[t]);
-                }
-            __syncthreads();
-        }
-    } else {
-        for (uint64_t i = (uint64_t)blockIdx.x * PART_NT + threadIdx.x; i < n; i += (uint64_t)gridDim.x * PART_NT) {
-            uint64_t h[WK];
+    // The list is mostly the same hot k-mers over and over (every scan wave drains its homopolymer cache, every
+    // level-2 workgroup its spill cache -- and, on skewed input, the chunks of records that found their sub-list
+    // full: the records of ONE level-2 workgroup side by side, i.e. the hot keys of one bucket).  A workgroup sums
+    // equal keys of its contiguous share in an LDS table that lives as long as the share: a hot key costs one
+    // same-address global atomic per WORKGROUP, not per entry.  A key that finds no place in 16 probes is
+    // inserted directly.  Multi-word keys: word 0 is claimed by CAS, the other words published behind a ready flag.
+    constexpr uint32_t DN = (RW == 1) ? 2048u : (RW == 2) ? 1024u : 512u;
+    __shared__ uint64_t s_k[DN * RW];
+    __shared__ unsigned long long s_c[DN];
+    __shared__ uint32_t s_r[(RW > 1) ? DN : 1];
+    for (uint32_t t = threadIdx.x; t < DN; t += PART_NT) { s_k[t * RW] = 0; s_c[t] = 0; if (RW > 1) s_r[t] = 0; }
+    __syncthreads();
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = min(n, (uint64_t)blockIdx.x * per), hi = min(n, lo + per);
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += PART_NT) {
+        const uint64_t d = cnt ? cnt[i] : 1ULL;
+        if (d == 0) continue;
+        uint64_t h[WK];
 #pragma unroll
-            for (int t = 0; t < WK; ++t) h[t] = rec[i * RW + t];
-            const uint64_t d = cnt ? cnt[i] : 1ULL;
-            if (d == 0 || (p.lg != p.l && owner_shard<WK>(p, h) != p.shard)) continue;
-            insert_key<WK>(p, h, d);
+        for (int t = 0; t < WK; ++t) h[t] = rec[i * RW + t];
+        if (p.lg != p.l && owner_shard<WK>(p, h) != p.shard) continue;
+        const uint64_t kk = h[0] ^ OVF_SALT;
+        uint64_t mixin = h[0];
+#pragma unroll
+        for (int t = 1; t < WK; ++t) mixin ^= h[t] * 0x9E3779B97F4A7C15ULL;
+        uint32_t slot = (uint32_t)(mix64(mixin) >> 40) & (DN - 1);
+        bool done = false;
+        for (int pr = 0; pr < 16 && kk != 0 && !done; ++pr) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_k[slot * RW]), 0ULL,
+                                                     (unsigned long long)kk);
+            if constexpr (RW == 1) {
+                if (old == 0ULL || old == kk) { atomicAdd(&s_c[slot], (unsigned long long)d); done = true; }
+            } else {
+                if (old == 0ULL) {
+#pragma unroll
+                    for (int t = 1; t < WK; ++t) s_k[slot * RW + t] = h[t];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __hip_atomic_store(&s_r[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    atomicAdd(&s_c[slot], (unsigned long long)d);
+                    done = true;
+                } else if (old == kk && __hip_atomic_load(&s_r[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    bool same = true;
+#pragma unroll
+                    for (int t = 1; t < WK; ++t) same &= (s_k[slot * RW + t] == h[t]);
+                    if (same) { atomicAdd(&s_c[slot], (unsigned long long)d); done = true; }
+                }
+                // (word 0 equal but not published yet, or another key: next place -- a key may then sit in two places
+                // of the table of this workgroup, which costs a second global insert, not a wrong count)
+            }
+            slot = (slot + 1) & (DN - 1);
         }
+        if (!done) insert_key<WK>(p, h, d);
     }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < DN; t += PART_NT)
+        if (s_c[t]) {
+            uint64_t h[WK];
+            h[0] = s_k[t * RW] ^ OVF_SALT;
+#pragma unroll
+            for (int u = 1; u < WK; ++u) h[u] = s_k[t * RW + u];
+            insert_key<WK>(p, h, s_c[t]);
+        }
 }
 
 // Write offsets from the level-1 histograms hist[b * G + g] (bucket-major), two steps:

@@ -816,6 +816,10 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1, RING_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2, RING_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4, RING_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
@@ -848,7 +852,7 @@ static int ensure_ovq(tsx_hip_map *m, size_t nq, int rw, hipStream_t st) {
     if (m->d_ovq_cnt) HIP_TRY(hipFree(m->d_ovq_cnt));
     m->d_ovq = nullptr; m->d_ovq_cnt = nullptr; m->ovq_queues = 0;
     HIP_TRY(hipMalloc((void **)&m->d_ovq, nq * OVQ_CAP * 8 * rw));
-    HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, nq * 4));
+    HIP_TRY(hipMalloc((void **)&m->d_ovq_cnt, nq * 4 + 512 * 4 + 64));   // (+ the skew flags of level 2, one per bucket, behind the counters)
     m->ovq_queues = nq * rw;
     return TSX_HIP_OK;
 }
@@ -893,7 +897,7 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pl.buf1, (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
                            (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
                            (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0,
-                           0, (unsigned long long *)nullptr, 0u, 0u, 0));
+                           0, (unsigned long long *)nullptr, 0u, 0u, 0, 0u, (const uint32_t *)nullptr));
         HIP_TRY(hipGetLastError());
     }
     }   // (fused: scan_part_kernel has left the level-1 sub-lists in buffer 1)
@@ -913,28 +917,44 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
         const uint32_t bits = ring_bits(pl.nb2);
         nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup (the fused scan's queues follow them)
+        // records per private chunk of the deferred list (mass spills of skewed input, see partition_ring_kernel): a
+        // quarter of the list shared out over the workgroups, a power of two in 64 .. 4096; 0: the list is too small
+        uint32_t dch = 0;
+        for (uint32_t c = 4096; c >= 64 && !dch; c >>= 1)
+            if ((uint64_t)c * nq2 * 4 <= (uint64_t)m->def_cap) dch = c;
         {
             const int rco = ensure_ovq(m, (size_t)nq2 + pl.G1, rw, st);
             if (rco != TSX_HIP_OK) return rco;
         }
+        // Which form of the level-2 kernel works (partition_ring_kernel: SKEW) is decided on the device: skew_probe_kernel
+        // samples every bucket and raises the flag -- the last word of the overflow-queue counters -- when it finds a hot
+        // key; both forms are launched, per bucket one of them returns at once.  TSX_HIP_SKEW=0|1 forces the plain / the skew form.
+        static int skew_force = -2;
+        if (skew_force == -2) { const char *e = getenv("TSX_HIP_SKEW"); skew_force = e ? atoi(e) : -1; }
+        uint32_t *d_skew = m->d_ovq_cnt + m->ovq_queues / rw;   // (ensure_ovq keeps one spare counter behind the queues')
+        if (skew_force >= 0) {
+            HIP_TRY(hipMemsetAsync(d_skew, skew_force ? 1 : 0, (size_t)pl.nb1 * 4, st));   // (any non-zero word means "skewed")
+        } else {
+            DISPATCH_RW(rw, hipLaunchKernelGGL((skew_probe_kernel<RWV>), dim3(pl.nb1), dim3(256), 0, st, (const uint64_t *)pl.buf1,
+                                               (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt,
+                                               (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr), pl.G1, pl.cap1, d_skew));
+        }
         // (512 lists of one-word records: the rings leave room for one workgroup per CU -- 1024 threads then)
+#define TSX_LEVEL2(RWV, NTV, SK, BITS)                                                                                          \
+        hipLaunchKernelGGL((partition_ring_kernel<RWV, NTV, SK>), dim3(pl.nb1 * pl.cpr2), dim3(NTV), part_lds(pl.nb2, BITS), st,  \
+                           pp, (const uint64_t *)pl.buf1, (const unsigned long long *)pl.c_bstart,                              \
+                           (const unsigned long long *)pl.c_bcnt, (uint64_t)0, pl.nb1, pl.cpr2, m->d_buf[0],                    \
+                           (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub,      \
+                           pl.nb2, (uint32_t)p.S, BITS, m->dbg, m->d_ovq, m->d_ovq_cnt, OVQ_CAP,                                 \
+                           (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr), pl.G1, pl.cap1, 0,                       \
+                           (unsigned long long *)nullptr, 0u, 0u, pre, dch, (const uint32_t *)d_skew)
         if (rw == 1 && part_lds(pl.nb2, bits) > ((size_t)80 << 10)) {
-            const uint32_t bits2 = 5;
-            hipLaunchKernelGGL((partition_ring_kernel<1, 1024>), dim3(pl.nb1 * pl.cpr2), dim3(1024),
-                               part_lds(pl.nb2, bits2), st, pp, (const uint64_t *)pl.buf1,
-                               (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
-                               pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
-                               (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits2, m->dbg,
-                               m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
-                               pl.G1, pl.cap1, 0, (unsigned long long *)nullptr, 0u, 0u, pre);
-        } else
-        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.nb1 * pl.cpr2), dim3(RING_NT),
-                           part_lds(pl.nb2, bits), st, pp, (const uint64_t *)pl.buf1,
-                           (const unsigned long long *)pl.c_bstart, (const unsigned long long *)pl.c_bcnt, (uint64_t)0,
-                           pl.nb1, pl.cpr2, m->d_buf[0], (const unsigned long long *)nullptr,
-                           (const unsigned long long *)nullptr, pl.c_seg, pl.cap_sub, pl.nb2, (uint32_t)p.S, bits, m->dbg,
-                           m->d_ovq, m->d_ovq_cnt, OVQ_CAP, (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr),
-                           pl.G1, pl.cap1, 0, (unsigned long long *)nullptr, 0u, 0u, pre));
+            TSX_LEVEL2(1, 1024, false, 5u);
+            TSX_LEVEL2(1, 1024, true, 5u);
+        } else {
+            DISPATCH_RW(rw, TSX_LEVEL2(RWV, RING_NT, false, bits); TSX_LEVEL2(RWV, RING_NT, true, bits));
+        }
+#undef TSX_LEVEL2
         HIP_TRY(hipGetLastError());
         lists = m->d_buf[0]; lists_start = nullptr; lists_cnt = pl.c_seg; lists_cap = pl.cap_sub; pieces = pl.cpr2;
     }
@@ -1374,7 +1394,7 @@ extern "C" int tsx_hip_shard_build_pieces_device(tsx_hip_map *m, const void *dev
                            (uint32_t)g, 1u, pl.buf1, (const unsigned long long *)nullptr,
                            (const unsigned long long *)nullptr, pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits,
                            m->dbg, m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
-                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum, 0u, (uint32_t)g, 0);
+                           (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, key_sum, 0u, (uint32_t)g, 0, 0u, (const uint32_t *)nullptr);
     } else {
         hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(PART_NT), 0, st, keys, (uint32_t)g, pl.nb1, (uint32_t)(m->p.l - pl.b1),
                            pl.d_hist, (const unsigned long long *)pl.c_rstart, (const unsigned long long *)pl.c_log, key_sum);
@@ -1457,7 +1477,7 @@ extern "C" int tsx_hip_shard_l1_window_device(tsx_hip_map *m, const void *dev_ke
                        pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits, m->dbg,
                        m->d_ovq + ((size_t)nq2 + (size_t)window * rw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)window * rw, OVQ_CAP,
                        (const unsigned long long *)nullptr, 0u, (uint64_t)0, 1, (unsigned long long *)dev_key_sum,
-                       window * rw, g1, 0);
+                       window * rw, g1, 0, 0u, (const uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
@@ -1625,7 +1645,7 @@ extern "C" int tsx_hip_shard_filter_device(tsx_hip_map *m, const void *dev_desc,
                        pl.c_l1, pl.cap1, pl.nb1, (uint32_t)(m->p.l - pl.b1), bits, m->dbg,
                        m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP, m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP,
                        (const unsigned long long *)lp.c_log, (uint32_t)greg, lp.log_cap, 1, (unsigned long long *)nullptr, slot,
-                       nslots, 0);
+                       nslots, 0, 0u, (const uint32_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
 }
@@ -2261,6 +2281,11 @@ extern "C" int tsx_hip_debug_counters(tsx_hip_map *m, uint64_t *out8) {
     if (rc != TSX_HIP_OK) return rc;
     for (int i = 0; i < 7; ++i) out8[i] = st[ST_DBG0 + i];
     out8[7] = 0;
+    if (m->d_def_n) {   // entries of the deferred list of the last partitioned pass
+        unsigned long long dn = 0;
+        HIP_TRY(hipMemcpy(&dn, m->d_def_n, 8, hipMemcpyDeviceToHost));
+        out8[7] = dn;
+    }
     return TSX_HIP_OK;
 }
 
@@ -2448,5 +2473,43 @@ extern "C" int tsx_hip_synth_fastq_device(uint64_t seed, uint64_t first_read, ui
     }
     if (hipStreamSynchronize(st) != hipSuccess) rc = TSX_HIP_EHIP;
     (void)hipFree(d_off);
+    return rc;
+}
+
+// Zipf-skewed reads written straight into device memory (BASELINE config 4; see synth_zipf_kernel).  thr: n_templates
+// ascending uint64 thresholds (host).  Sizing call: dev_out == NULL.
+extern "C" int tsx_hip_synth_zipf_device(uint64_t seed, uint64_t n_reads, uint32_t read_len, uint32_t n_templates,
+                                         const uint64_t *thr, void *dev_out, size_t cap, uint64_t *bytes_out, int device,
+                                         void *stream) {
+    if (read_len < 1 || read_len > (1u << 20) || n_templates < 1 || !thr) return TSX_HIP_EINVAL;
+    std::vector<uint64_t> offs(n_reads + 1);
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        offs[r] = total;
+        total += 2 + dec_digits(r) + 1 + 2 * (uint64_t)read_len + 4;
+    }
+    offs[n_reads] = total;
+    if (bytes_out) *bytes_out = total;
+    if (!dev_out) return TSX_HIP_OK;
+    if (total > cap) return TSX_HIP_ERANGE;
+    if (n_reads == 0) return TSX_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TSX_HIP_ENODEVICE;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *d_off = nullptr, *d_thr = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_off, (n_reads + 1) * 8));
+    if (hipMalloc((void **)&d_thr, (size_t)n_templates * 8) != hipSuccess) { (void)hipFree(d_off); return TSX_HIP_ENOMEM; }
+    int rc = TSX_HIP_OK;
+    if (hipMemcpyAsync(d_off, offs.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_thr, thr, (size_t)n_templates * 8, hipMemcpyHostToDevice, st) != hipSuccess) rc = TSX_HIP_EHIP;
+    if (rc == TSX_HIP_OK) {
+        const int grid = (int)std::min<uint64_t>(n_reads, 65536);
+        hipLaunchKernelGGL(synth_zipf_kernel, dim3(grid), dim3(NT), 0, st, seed, n_reads, read_len, n_templates,
+                           (const uint64_t *)d_thr, (const uint64_t *)d_off, (uint8_t *)dev_out);
+        if (hipGetLastError() != hipSuccess) rc = TSX_HIP_EHIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) rc = TSX_HIP_EHIP;
+    (void)hipFree(d_off); (void)hipFree(d_thr);
     return rc;
 }
