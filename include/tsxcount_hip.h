@@ -89,9 +89,9 @@ int tsx_hip_decode(const uint64_t *limbs, int k, char *out);
  *   overflow_l   log2 slots of the secondary array; 0 = max(10, l-4).
  *   hash_seed    seed of the bijective GF(2) mapping; the reference draws it
  *                from time(NULL) (BijectiveKMapping.h:84).  The matrix is dense:
- *                multiplication by a random element of GF(2^2k) for k <= 32, L*U of
- *                two random unit triangular matrices above (the reference uses U
- *                alone, which makes the slot a function of the first l/2 bases only).
+ *                multiplication by a random element of GF(2^2k), for every k <= 127
+ *                (the reference uses a unit triangular matrix, which makes the slot a
+ *                function of the first l/2 bases only).
  *   device       HIP device ordinal.
  */
 int tsx_hip_create(tsx_hip_map **out, int k, int l, int storagebits, int overflow_l,
@@ -163,7 +163,7 @@ int tsx_hip_get_timing(tsx_hip_map *m, double *line_ms, double *count_ms, double
                        uint64_t *launches);
 /*
  * The same accumulation split per stage: stage_ms[7] = line passes, scan kernel
- * (count_fastq_kernel or scan_log_kernel), radix level 1 (offsets + partition; in a sharded run also the
+ * (count_fastq_kernel, or strip_desc_kernel + the walk), radix level 1 (offsets + partition; in a sharded run also the
  * histogram of the received keys), radix level 2, the segment build kernel, the gap between the end of the
  * scan and the start of the partition phase (0 except in a sharded run, where the owner split and the key
  * exchange lie there), and the inserts that wait for the build (overflow queues, deferred list).

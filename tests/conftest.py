@@ -17,9 +17,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _torch_gpu_first():
-    """On a GPU box bring torch's device context up before the first test: the tests mix torch tensors (device
-    buffers, collectives) with the HIP library, and torch failed to find the GPU once ("No HIP GPUs are
-    available") when its lazy initialisation came after ~90 tests of the library alone."""
+    """On a GPU box bring torch up before the first test.  Cause (round 3, checked with readelf): this image holds TWO copies
+    of the HIP runtime with the same SONAMEs -- /opt/rocm-7.2.0/lib/libamdhip64.so.7 + libhsa-runtime64.so.1, which
+    libtsxcount_hip.so is linked against, and torch's own bundled pair (ROCm 7.0, torch/lib, RPATH $ORIGIN).  The dynamic
+    loader keeps whichever is loaded FIRST for the whole process.  When ~90 tests of the library alone ran before the
+    first torch tensor, the system runtime was the loaded one and torch 2.10+rocm7.0 did not come up on it ("No HIP GPUs
+    are available", gpurun_out/r2_pytest3.log); with torch first its bundled runtime serves both, which the library --
+    plain HIP runtime API -- is happy with.  Nothing in the library touches HIP_VISIBLE_DEVICES or the device state.
+    bench.py and the workers import torch first for the same reason; a C++ host without torch has one runtime only."""
     try:
         import torch
         if torch.cuda.is_available():

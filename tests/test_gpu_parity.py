@@ -353,7 +353,7 @@ def test_hot_keys_overflow_sub_lists_two_radix_levels(T):
 
 
 def test_fused_scan_sub_list_overflow(T, monkeypatch):
-    """scan_part_kernel keeps one fixed-capacity sub-list per (workgroup, level-1 bucket).  Shrunk to 16 keys
+    """walk_part_kernel keeps one fixed-capacity sub-list per (workgroup, level-1 bucket).  Shrunk to 16 keys
     nearly every key finds its sub-list full and takes the spill cache / overflow queue / deferred list; the
     counts must not change.  Also the same text with the fused kernel switched off (key log + separate level 1)."""
     from tsxcount_amd import synth
@@ -362,18 +362,16 @@ def test_fused_scan_sub_list_overflow(T, monkeypatch):
     st = assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
     assert st["fallback_inserts"] > 1000
     assert_same_as_oracle(T, text, 20, 24, 4, path="partitioned")
-    monkeypatch.setenv("TSX_HIP_FUSE", "1")      # the one-kernel form (scan_part_kernel), sub-lists overflowing as well
-    assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
     monkeypatch.delenv("TSX_HIP_CAP1")
     monkeypatch.setenv("TSX_HIP_FUSE", "0")
     assert_same_as_oracle(T, text, 31, 23, 0, path="partitioned")
     monkeypatch.delenv("TSX_HIP_FUSE")
 
 
-@pytest.mark.parametrize("fuse", ["2", "2L", "1", "0"])
+@pytest.mark.parametrize("fuse", ["2", "2L", "0"])
 def test_fused_and_unfused_scan_agree_entry_for_entry(T, monkeypatch, fuse):
-    """Two radix levels, pieces of the host entry point (segments rebuilt from their previous content): the three
-    forms of the scan (2: strip descriptions + walk, 1: one fused kernel, 0: key log + level 1) leave the same table."""
+    """Two radix levels, pieces of the host entry point (segments rebuilt from their previous content): the forms of the
+    scan (2: strip descriptions + the walk fused with level 1, 0: strip descriptions + key log + level 1) leave the same table."""
     from tsxcount_amd import synth
     if fuse == "2L":   # the two-kernel form with four strips per description
         monkeypatch.setenv("TSX_HIP_LOCAL_LONG", "1")
@@ -523,13 +521,13 @@ def test_rolling_hash_every_multi_limb_k(T, k):
 
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_fuzzed_record_structure_two_radix_levels(T, seed, monkeypatch):
-    """The ragged texts through the scan forms of a table split by two radix levels (l = 23): strip descriptions +
-    walk (default) and the one-kernel fused form; k >= 12 keeps 2k >= l + 1 (the slot stores key bits above l)."""
+    """The ragged texts through the scan forms of a table split by two radix levels (l = 23): strip descriptions + the
+    walk fused with level 1 (default) and the key-log form; k >= 12 keeps 2k >= l + 1 (the slot stores key bits above l)."""
     rng = np.random.default_rng(9000 + seed)
     k = int(rng.integers(12, 33))
     text = b"".join(_fuzz_text(rng) for _ in range(int(rng.integers(2, 8))))
     assert_same_as_oracle(T, text, k, 23, 0, path="partitioned")
-    monkeypatch.setenv("TSX_HIP_FUSE", "1")
+    monkeypatch.setenv("TSX_HIP_FUSE", "0")
     assert_same_as_oracle(T, text, k, 23, 0, path="partitioned")
     monkeypatch.delenv("TSX_HIP_FUSE")
 

@@ -59,7 +59,7 @@ struct TableParams {
     unsigned long long *stats;  // ST_N device counters
     const uint64_t *lut;        // hash LUT   [groups][1<<g][WK]
     const uint64_t *ilut;       // inverse    [groups][1<<g][WK]
-    const uint64_t *roll;       // one-limb keys: sliding-window update table [64] (scan_log_kernel), else null
+    const uint64_t *roll;       // one-limb keys: sliding-window update table [64] (the walk kernels), else null
     uint64_t slot_mask;         // 2^l - 1
     uint64_t seg_mask;          // 2^S - 1: probing never leaves the 2^S-slot segment of its home slot
     uint8_t *seg_dirty;         // one byte per segment: 1 once the segment holds anything
@@ -174,7 +174,7 @@ __device__ inline uint64_t sec_get(const TableParams &p, uint64_t pos) {
 // Probe sequence: the reference's pos = (key + i(i+1)/2) mod 2^l
 // (TSXHashMap.h:759-778,1046-1054) with the wrap-around taken inside the
 // 2^S-slot segment of the home slot, so that one workgroup can own a segment
-// (build_segments_kernel) and still probe exactly like the atomic path.
+// (build_segments_stream_kernel) and still probe exactly like the atomic path.
 // For l <= S this is the reference's formula.
 __device__ __forceinline__ uint64_t probe_pos(const TableParams &p, uint64_t pos0, uint32_t i) {
     return (pos0 & ~p.seg_mask) | ((pos0 + (((uint64_t)i * (i + 1)) >> 1)) & p.seg_mask);

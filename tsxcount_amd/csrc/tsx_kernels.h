@@ -3,8 +3,9 @@
 //   line_count_kernel   FASTQ pass 1: non-empty line terminators per tile
 //   line_*scan* kernels FASTQ pass 2: exclusive scan -> line index at tile start
 //   count_fastq_kernel  FASTQ pass 3, atomic path: scan + 2-bit encode + hash + dedup + insert
-//   scan_log_kernel     FASTQ pass 3, partitioned path (k <= 32): strips of 16 positions per
-//                       lane, rolling hash, per-wave key log (tsx_partition.h takes it from there)
+//   strip_desc_kernel   FASTQ pass 3, partitioned path: the tile front end -> 16-byte strip descriptions
+//   walk_log_kernel     ... walked with every lane busy: rolling hash, per-wave key log (tsx_partition.h takes it
+//                       from there; walk_part_kernel there is the walk fused with radix level 1); *_wide_*: k > 32
 //   add_kmers_kernel    addKmer for a batch of encoded k-mers
 //   get_counts_kernel   getKmerCount(kmer) for a batch
 //   occupied_kernel     getKmerCount() (occupied slots)
@@ -330,300 +331,10 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
     if (lane == 0 && added) atomicAdd(&p.stats[ST_KMERS], added);
 }
 
-// Pass 3 of the partitioned path (k <= 32): scan -> 2-bit encode -> hash -> key log.
-// Same tile front end as count_fastq_kernel; what differs is what happens to a k-mer:
-//   * every LANE walks a strip of 16 consecutive start positions.  For one-limb keys the
-//     mapping is x -> c*x in GF(2^2k) (make_mapping), so the hash of the next window follows
-//     from the current one with ONE 64-entry table lookup,
-//         h' = (h >> 2) ^ roll[(h & 3) | out_base << 2 | in_base << 4],
-//     instead of eight LUT lookups per k-mer; only the first window of a strip is hashed in
-//     full.  Validity of the 16 windows (no newline inside, sequence line of a 4-line
-//     record, inside this piece) is one bit mask per strip, built with shifts;
-//   * nothing is inserted and nothing is deduplicated per workgroup -- duplicates are
-//     summed where they meet anyway, in the LDS segment build;
-//   * every WAVE owns a region of the key log, so keys are appended with one ballot and
-//     scalar arithmetic: no atomics, no workgroup barrier inside the strip loop (two
-//     barriers per 4 KiB tile in all);
-//   * equal consecutive k-mers (homopolymer runs) are counted in the lane, merged across
-//     the wave and folded into the wave's 8-entry hot cache with their total;
-//   * the level-1 histogram of each region is kept in LDS (exact offsets downstream).
-// Regions and histogram columns are indexed by blockIdx.x * 4 + wave.
-__global__ __launch_bounds__(NT, 4) void scan_log_kernel(TableParams p, const uint8_t *buf, uint64_t n,
-                                                         uint64_t own_end, int head_open, const uint32_t *tile_line,
-                                                         uint64_t ntiles, int dbg, uint64_t *log, uint64_t log_cap,
-                                                         unsigned long long *log_cnt, uint32_t *hist, uint32_t hist_nb,
-                                                         uint32_t hist_shift) {
-    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
-    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
-    __shared__ uint64_t s_le[TILE / 64];
-    __shared__ uint8_t s_lb[TILE / 16];
-    __shared__ uint32_t s_wsum[NT / 64];
-    constexpr int HOT_N = 8;
-    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hist[(NT / 64) * 512];  // level-1 fan-out <= 512
-    __shared__ uint64_t s_roll[64];
-    __shared__ uint64_t s_homh[4];     // hashes of the four homopolymer k-mers
-    extern __shared__ uint64_t s_lut[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lut_words = p.groups * (1 << p.g);
-    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
-    for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
-    if (tid < 64) s_roll[tid] = p.roll[tid];
-    if (tid < 4) {   // straight from the global LUT: s_lut is not complete before the first barrier
-        const uint64_t x[1] = {(0x5555555555555555ULL * (uint64_t)tid) & p.top_mask};
-        uint64_t hh[1];
-        hash_apply<1>(p, p.lut, x, hh);
-        s_homh[tid] = hh[0];
-    }
-    if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
-    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
-    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
-    unsigned long long added = 0;
-    const uint32_t k = (uint32_t)p.k;
-    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
-    uint64_t *my_log = log + (uint64_t)region * log_cap;
-    uint32_t *my_hist = s_hist + wave * 512;
-    uint32_t fill = 0;  // wave-uniform
-    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
-    // windows that may start at all: inside the text and inside this piece
-    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
-
-    // Rare ways out (log region full, hot cache full, end-of-kernel hot cache drain): the key joins the
-    // deferred list (tsx_device.h), out of line and fed from the kernel-argument segment (TableParams is the
-    // first kernel argument) so that nothing of it occupies registers inside the strip loop.
-    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    auto side_insert = [&](uint64_t hkey, uint64_t d) {
-        if (dbg & 1) return;
-        defer_append1(pk, hkey, d);
-    };
-
-    // the tile's 16 bytes of this lane and "the byte before them is a newline" are loaded one tile ahead (the
-    // first version waited for two dependent loads at the top of every tile)
-    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
-    bool cur_pnl = true;
-    uint32_t cur_line = 0;
-    if ((uint64_t)blockIdx.x < ntiles) {
-        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
-        cur_line = tile_line[blockIdx.x];
-        cur = load16(buf, off, n);
-        cur_pnl = prev_is_nl(buf, off, n, head_open);
-        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
-    }
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t base = tile * TILE;
-        lds_barrier();  // previous tile's LDS fully consumed
-        {
-            uint32_t nl, le, code;
-            classify16(cur, cur_pnl, nl, le, code);
-            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
-            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
-            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
-            if (tid < HALO / 16) {
-                uint32_t hnl, hle, hcode;
-                classify16(hcur, false, hnl, hle, hcode);
-                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
-                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
-            }
-            const uint32_t c = __popc(le);
-            const uint32_t inc = wave_incl_scan(c);
-            if (lane == 63) s_wsum[wave] = inc;
-            lds_barrier();
-            uint32_t woff = cur_line;   // lines before the tile, loaded a tile ahead like its text
-            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
-            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
-        }
-        {
-            const uint64_t nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
-                cur_line = tile_line[nt];
-                cur = load16(buf, off, n);
-                cur_pnl = prev_is_nl(buf, off, n, head_open);
-                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
-            }
-        }
-        lds_barrier();
-
-        // ---- this lane's strip: start positions s .. s+15 of the tile -------------------
-        const uint32_t s0 = (uint32_t)tid * 16;
-        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
-        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
-        // newline flags of bytes [s, s+64)
-        uint64_t m;
-        {
-            const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
-            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2];
-            m = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
-        }
-        // bad_j = a newline in [s+j, s+j+k): OR of m >> t for t < k, by doubling
-        uint64_t r = m;
-        uint32_t span = 1;
-        while (span * 2 <= k) { r |= r >> span; span *= 2; }
-        if (span < k) r |= r >> (k - span);
-        // line index of position j = lb + (line ends before j): two prefix-parity passes give it mod 4
-        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
-        const uint32_t lb = s_lb[tid];
-        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
-        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
-        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
-        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
-        const uint64_t g0 = base + s0;
-        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
-        const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;   // FASTA: every second line is a sequence
-        const uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);   // sequence line, no newline, in range
-        added += (unsigned long long)__popc(vm);
-        // header, '+' and quality lines are half of a FASTQ text: skip waves without a k-mer start
-        if (__ballot(vm != 0u) == 0ULL) continue;
-
-        uint64_t h = 0;
-        if (vm) {
-            uint64_t x[1], hh[1];
-            extract_kmer<1>(s_codes, s0, p.top_mask, x);
-            hash_apply<1>(p, (const uint64_t *)s_lut, x, hh);
-            h = hh[0];
-        }
-        // bases leaving (s+j) and entering (s+j+k) when the window moves from j to j+1
-        const uint32_t cw0 = codes32[tid];
-        uint32_t inc;
-        {
-            const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
-            const uint32_t w0 = codes32[tid + ws], w1 = (ws < 2u) ? codes32[tid + ws + 1] : 0u;
-            inc = __funnelshift_r(w0, w1, sh);
-        }
-        // Homopolymer k-mers (all k bases equal) are the one kind of k-mer that repeats back to back --
-        // the A-tails of reads -- and there are only four of them.  They are found on the 2-bit codes,
-        // not on the hashes: "base i differs from base i+1" is a bit per base, OR-smeared over k-1 bases.
-        // Their occurrences are counted per lane, summed over the wave and folded into the wave's hot
-        // cache under the four precomputed hashes; everything else is logged.
-        uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
-        {
-            const uint64_t lo = (uint64_t)cw0 | ((uint64_t)codes32[tid + 1] << 32), hi = codes32[tid + 2];
-            const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
-            uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
-            uint32_t span = 1;   // bases covered by the smear so far; k - 1 adjacent pairs must agree
-            while (span * 2 <= k - 1) {
-                const uint32_t sh = 2u * span;
-                rlo |= (rlo >> sh) | (rhi << (64u - sh));
-                rhi |= rhi >> sh;
-                span *= 2;
-            }
-            if (span < k - 1) {
-                const uint32_t sh = 2u * (k - 1 - span);
-                rlo |= (rlo >> sh) | (rhi << (64u - sh));
-            }
-            uint32_t x = ~(uint32_t)rlo & 0x55555555u;   // even bits -> 16 contiguous bits
-            x = (x | (x >> 1)) & 0x33333333u;
-            x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-            x = (x | (x >> 4)) & 0x00FF00FFu;
-            homm = (x | (x >> 8)) & 0xFFFFu;
-        }
-        const uint32_t hv = vm & homm;
-        const uint32_t single = vm & ~homm;
-        if (__ballot(hv != 0u)) {
-            for (uint32_t b = 0; b < 4; ++b) {   // which of the four: the base at the position
-                uint32_t e = cw0 ^ (0x55555555u * b);
-                uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
-                y = (y | (y >> 1)) & 0x33333333u;
-                y = (y | (y >> 2)) & 0x0F0F0F0Fu;
-                y = (y | (y >> 4)) & 0x00FF00FFu;
-                y = (y | (y >> 8)) & 0xFFFFu;
-                uint32_t tot = (uint32_t)__popc(hv & y);
-                if (__ballot(tot != 0u) == 0ULL) continue;
-                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                if (lane == 0) {
-                    const uint64_t key = s_homh[b];
-                    uint64_t *hkey = s_hot_key + wave * HOT_N;
-                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
-                    int at = -1;
-                    for (int q = 0; q < HOT_N; ++q)
-                        if (hcnt[q] && hkey[q] == key) { at = q; break; }
-                    if (at < 0)
-                        for (int q = 0; q < HOT_N; ++q)
-                            if (!hcnt[q]) { at = q; hkey[q] = key; break; }
-                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
-                    else side_insert(key, tot);
-                }
-            }
-        }
-        // The strip is walked in two halves of 8 positions (the hash rolls on across them): pass A
-        // rolls and keeps the 8 hashes, pass B appends them to this wave's log region, one contiguous
-        // piece per position.
-        for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
-            const uint32_t s8 = (single >> j0) & 0xFFu;
-            if (__ballot(s8 != 0u) == 0ULL) {   // nothing to log in this half: only roll on
-                if (j0 == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
-                                             (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
-                        h = (h >> 2) ^ s_roll[idx];
-                    }
-                }
-                continue;
-            }
-            uint64_t hs[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hs[j] = h;
-                if (j0 + j < 15) {
-                    const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
-                                         (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
-                    h = (h >> 2) ^ s_roll[idx];
-                }
-            }
-            if (fill + 64u * 8u <= cap32) {   // the usual case: the region has room for whatever this half logs
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const bool em = (s8 >> j) & 1u;
-                    const unsigned long long mk = __ballot(em);
-                    if (mk) {
-                        if (em) {
-                            const uint64_t key = hs[j];
-                            my_log[fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL))] = key;
-                            atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
-                        }
-                        fill += (uint32_t)__builtin_popcountll(mk);
-                    }
-                }
-            } else {
-                for (int j = 0; j < 8; ++j) {
-                    const bool em = (s8 >> j) & 1u;
-                    const unsigned long long mk = __ballot(em);
-                    if (mk) {
-                        if (em) {
-                            uint64_t key = hs[0];
-#pragma unroll
-                            for (int t = 1; t < 8; ++t) key = (j == t) ? hs[t] : key;
-                            const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & ((1ULL << lane) - 1ULL));
-                            if (at < cap32) {
-                                my_log[at] = key;
-                                atomicAdd(&my_hist[(uint32_t)(key >> hist_shift) & (hist_nb - 1)], 1u);
-                            } else {
-                                side_insert(key, 1);  // region full: deferred list (or the exchanged hot list)
-                            }
-                        }
-                        fill += (uint32_t)__builtin_popcountll(mk);
-                    }
-                }
-            }
-        }
-    }
-    lds_barrier();
-    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
-    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
-    if (lane == 0) {
-        if (added) atomicAdd(&p.stats[ST_KMERS], added);
-        log_cnt[region] = min(fill, cap32);
-    }
-    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
-}
-
 // ---- the scan in two kernels: describe the strips, then walk them ------------------------------------------
-// Lines of a read file are about as long as a wave's share of a tile (1 KiB), so nearly every wave of
-// scan_log_kernel / scan_part_kernel holds some sequence bytes and walks its 16 positions with half of its lanes
-// in '+'/quality lines: the roll and append instructions -- two thirds of those kernels -- run at 50 % lane use.
+// Lines of a read file are about as long as a wave's share of a tile (1 KiB), so nearly every wave of a kernel that
+// scans AND walks (the one-kernel forms of rounds 1 and 2) holds some sequence bytes and walks its 16 positions with half
+// of its lanes in '+'/quality lines: the roll and append instructions -- two thirds of such a kernel -- run at 50 % lane use.
 // strip_desc_kernel does the tile front end only (classify, line index, validity mask) and writes a 16-byte
 // DESCRIPTION of every strip that holds a k-mer start -- the 48 bases from its first position as 2-bit codes and
 // the 16 validity bits -- to its wave's region of a descriptor array; walk_part_kernel (tsx_partition.h) reads
@@ -694,7 +405,7 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
             }
         }
         lds_barrier();
-        // ---- this lane's strip: start positions s .. s+15 of the tile (as in scan_log_kernel) -----------
+        // ---- this lane's strip: start positions s .. s+15 of the tile -----------
         const uint32_t s0 = (uint32_t)tid * 16;
         const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
         const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
@@ -748,8 +459,7 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
     }
 }
 
-// walk_log_kernel: scan_log_kernel's walk fed from strip descriptions (strip_desc_kernel above) instead of its own
-// tile front end -- one description per lane, every lane busy, no barrier after the set-up (a wave reads descriptor
+// walk_log_kernel: the walk into a key log, fed from strip descriptions (strip_desc_kernel above) -- one description per lane, every lane busy, no barrier after the set-up (a wave reads descriptor
 // regions w, w + G, ... and appends to its own log region; the histogram is the wave's).  Used where the keys must
 // come out as a packed log: sharded scans (histogram by owner) and tables that need one radix level.
 __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
@@ -982,242 +692,6 @@ __device__ __forceinline__ void shr_or3(uint64_t (&r)[3], uint32_t s) {
     r[2] |= r[2] >> s;
 }
 
-// Pass 3 of the partitioned path for multi-limb keys (k > 32; WK = 2..4).  Same tile front end and the same
-// strip idea as scan_log_kernel -- a lane walks 16 consecutive start positions, hashes the first window with
-// the LUT and every further one with the sliding update of x -> c*x in GF(2^2k),
-//     h' = (h >> 2) ^ roll[(h & 3) | out_base << 2 | in_base << 4]      (WK limbs per table entry),
-// and appends the hashes to its wave's log region with one ballot per position.  What differs:
-//   * the newline mask of a strip spans 16 + k - 1 <= 142 bytes: three words, smeared by doubling;
-//   * homopolymer k-mers (the A-tails) are recognised on the HASH: the mapping is a bijection, so
-//     h == hash(b repeated k times) says exactly that all k bases equal b.  They are counted per lane,
-//     summed over the wave and folded into the wave's hot cache; everything else is logged;
-//   * one position at a time (eight WK-limb hashes per lane would not fit the register budget).
-template <int WK>
-__global__ __launch_bounds__(NT, 2) void scan_log_wide_kernel(TableParams p, const uint8_t *buf, uint64_t n,
-                                                              uint64_t own_end, int head_open,
-                                                              const uint32_t *tile_line, uint64_t ntiles, int dbg,
-                                                              uint64_t *log, uint64_t log_cap,
-                                                              unsigned long long *log_cnt, uint32_t *hist,
-                                                              uint32_t hist_nb, uint32_t hist_shift) {
-    constexpr int RW = RecWords<WK>::value;
-    __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
-    __shared__ uint64_t s_nl[(TILE + HALO) / 64 + 3];
-    __shared__ uint64_t s_le[TILE / 64];
-    __shared__ uint8_t s_lb[TILE / 16];
-    __shared__ uint32_t s_wsum[NT / 64];
-    constexpr int HOT_N = 8;
-    __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N * WK];
-    __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
-    __shared__ uint32_t s_hist[(NT / 64) * 512];
-    __shared__ uint64_t s_roll[64 * WK];
-    __shared__ uint64_t s_homh[4 * WK];
-    extern __shared__ uint64_t s_lut[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lut_words = p.groups * (1 << p.g) * WK;
-    for (int i = tid; i < lut_words; i += NT) s_lut[i] = p.lut[i];
-    for (int i = tid; i < (NT / 64) * 512; i += NT) s_hist[i] = 0;
-    for (int i = tid; i < 64 * WK; i += NT) s_roll[i] = p.roll[i];
-    if (tid < 4) {   // straight from the global LUT: s_lut is not complete before the first barrier
-        uint64_t x[WK], hh[WK];
-#pragma unroll
-        for (int t = 0; t < WK; ++t) x[t] = 0x5555555555555555ULL * (uint64_t)tid;
-        x[WK - 1] &= p.top_mask;
-        hash_apply<WK>(p, p.lut, x, hh);
-#pragma unroll
-        for (int t = 0; t < WK; ++t) s_homh[tid * WK + t] = hh[t];
-    }
-    if (tid < (NT / 64) * HOT_N) s_hot_cnt[tid] = 0;
-    if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
-    if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
-    unsigned long long added = 0;
-    const uint32_t k = (uint32_t)p.k;
-    const uint32_t G = gridDim.x * (NT / 64), region = blockIdx.x * (NT / 64) + wave;
-    uint64_t *my_log = log + (uint64_t)region * log_cap * RW;
-    uint32_t *my_hist = s_hist + wave * 512;
-    uint32_t fill = 0;  // wave-uniform, in records
-    const uint32_t cap32 = (uint32_t)min(log_cap, (uint64_t)0xFFFFFFFFu);
-    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
-    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint64_t lt = (1ULL << lane) - 1ULL;
-
-    // text loaded one tile ahead, as in scan_log_kernel
-    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
-    bool cur_pnl = true;
-    uint32_t cur_line = 0;
-    if ((uint64_t)blockIdx.x < ntiles) {
-        const uint64_t off = (uint64_t)blockIdx.x * TILE + (uint64_t)tid * 16;
-        cur_line = tile_line[blockIdx.x];
-        cur = load16(buf, off, n);
-        cur_pnl = prev_is_nl(buf, off, n, head_open);
-        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * TILE + TILE + (uint64_t)tid * 16, n);
-    }
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t base = tile * TILE;
-        lds_barrier();  // previous tile's LDS fully consumed
-        {
-            uint32_t nl, le, code;
-            classify16(cur, cur_pnl, nl, le, code);
-            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
-            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
-            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
-            if (tid < HALO / 16) {
-                uint32_t hnl, hle, hcode;
-                classify16(hcur, false, hnl, hle, hcode);
-                reinterpret_cast<uint32_t *>(s_codes)[TILE / 16 + tid] = hcode;
-                reinterpret_cast<uint16_t *>(s_nl)[TILE / 16 + tid] = (uint16_t)hnl;
-            }
-            const uint32_t c = __popc(le);
-            const uint32_t inc = wave_incl_scan(c);
-            if (lane == 63) s_wsum[wave] = inc;
-            lds_barrier();
-            uint32_t woff = cur_line;   // lines before the tile, loaded a tile ahead like its text
-            for (int w = 0; w < wave; ++w) woff += s_wsum[w];
-            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
-        }
-        {
-            const uint64_t nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                const uint64_t off = nt * TILE + (uint64_t)tid * 16;
-                cur_line = tile_line[nt];
-                cur = load16(buf, off, n);
-                cur_pnl = prev_is_nl(buf, off, n, head_open);
-                if (tid < HALO / 16) hcur = load16(buf, nt * TILE + TILE + (uint64_t)tid * 16, n);
-            }
-        }
-        lds_barrier();
-
-        const uint32_t s0 = (uint32_t)tid * 16;
-        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
-        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
-        // newline flags of bytes [s0, s0 + 160): a window of position j <= 15 reaches byte s0 + 15 + k - 1 <= s0 + 141
-        uint64_t r[3];
-        {
-            const uint32_t w = (uint32_t)tid >> 1, sh = ((uint32_t)tid & 1u) * 16u;
-            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2], a3 = nl32[w + 3], a4 = nl32[w + 4],
-                           a5 = nl32[w + 5];
-            r[0] = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
-            r[1] = (uint64_t)__funnelshift_r(a2, a3, sh) | ((uint64_t)__funnelshift_r(a3, a4, sh) << 32);
-            r[2] = (uint64_t)__funnelshift_r(a4, a5, sh);
-        }
-        {   // bad_j = a newline in [s0+j, s0+j+k): OR of the mask shifted by 0..k-1, by doubling
-            uint32_t span = 1;
-            while (span * 2 <= k) { shr_or3(r, span); span *= 2; }
-            if (span < k) shr_or3(r, k - span);
-        }
-        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
-        const uint32_t lb = s_lb[tid];
-        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
-        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
-        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
-        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);       // bits 0 and 1 of the line index
-        const uint64_t g0 = base + s0;
-        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
-        const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;   // FASTA: every second line is a sequence
-        const uint32_t vm = ~(uint32_t)r[0] & b0 & nb1 & ((1u << jmax) - 1u);   // sequence line, no newline, in range
-        added += (unsigned long long)__popc(vm);
-        if (__ballot(vm != 0u) == 0ULL) continue;   // header, '+' and quality lines: nothing starts here
-
-        uint64_t h[WK];
-#pragma unroll
-        for (int t = 0; t < WK; ++t) h[t] = 0;
-        if (vm) {
-            uint64_t x[WK];
-            extract_kmer<WK>(s_codes, s0, p.top_mask, x);
-            hash_apply<WK>(p, (const uint64_t *)s_lut, x, h);
-        }
-        // bases leaving (s0+j) and entering (s0+j+k) when the window moves from j to j+1
-        const uint32_t cw0 = codes32[tid];
-        uint32_t inc;
-        {
-            const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
-            inc = __funnelshift_r(codes32[tid + ws], codes32[tid + ws + 1], sh);
-        }
-        uint32_t homcnt = 0;   // four 8-bit counters: homopolymer k-mers of base b seen in this strip
-        for (uint32_t j = 0; j < 16; ++j) {
-            const bool valid = (vm >> j) & 1u;
-            const uint32_t ob = __builtin_amdgcn_ubfe(cw0, 2u * j, 2u);
-            bool hom = valid && h[0] == s_homh[ob * WK];
-            if (hom) {
-#pragma unroll
-                for (int t = 1; t < WK; ++t) hom &= (h[t] == s_homh[ob * WK + t]);
-            }
-            homcnt += hom ? (1u << (8u * ob)) : 0u;
-            const bool em = valid && !hom;
-            const unsigned long long mk = __ballot(em);
-            if (mk) {
-                if (em) {
-                    const uint32_t at = fill + (uint32_t)__builtin_popcountll(mk & lt);
-                    if (at < cap32) {
-                        uint64_t *o = my_log + (uint64_t)at * RW;
-#pragma unroll
-                        for (int t = 0; t < RW; ++t) o[t] = (t < WK) ? h[t < WK ? t : 0] : 0ULL;
-                        atomicAdd(&my_hist[(uint32_t)(h[0] >> hist_shift) & (hist_nb - 1)], 1u);
-                    } else if (!(dbg & 1)) {
-                        uint64_t rec[RW];
-#pragma unroll
-                        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? h[t < WK ? t : 0] : 0ULL;
-                        defer_append<RW>(pk, rec, 1);   // region full
-                    }
-                }
-                fill += (uint32_t)__builtin_popcountll(mk);
-            }
-            if (j < 15) {
-                const uint32_t idx = ((uint32_t)h[0] & 3u) | (ob << 2) | (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
-#pragma unroll
-                for (int t = 0; t < WK; ++t) {
-                    uint64_t v = h[t] >> 2;
-                    if (t + 1 < WK) v |= h[t + 1] << 62;
-                    h[t] = v ^ s_roll[idx * WK + t];
-                }
-            }
-        }
-        if (__ballot(homcnt != 0u)) {
-            for (uint32_t b = 0; b < 4; ++b) {
-                uint32_t tot = (homcnt >> (8u * b)) & 0xFFu;
-                if (__ballot(tot != 0u) == 0ULL) continue;
-                for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                if (lane == 0) {
-                    uint64_t *hkey = s_hot_key + (size_t)wave * HOT_N * WK;
-                    uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
-                    int at = -1;
-                    for (int q = 0; q < HOT_N && at < 0; ++q) {
-                        if (!hcnt[q]) continue;
-                        bool same = true;
-                        for (int t = 0; t < WK; ++t) same &= (hkey[q * WK + t] == s_homh[b * WK + t]);
-                        if (same) at = q;
-                    }
-                    if (at < 0)
-                        for (int q = 0; q < HOT_N; ++q)
-                            if (!hcnt[q]) {
-                                at = q;
-                                for (int t = 0; t < WK; ++t) hkey[q * WK + t] = s_homh[b * WK + t];
-                                break;
-                            }
-                    if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
-                    else if (!(dbg & 1)) {
-                        uint64_t rec[RW];
-                        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? s_homh[b * WK + (t < WK ? t : 0)] : 0ULL;
-                        defer_append<RW>(pk, rec, tot);
-                    }
-                }
-            }
-        }
-    }
-    lds_barrier();
-    if (tid < (NT / 64) * HOT_N && s_hot_cnt[tid] && !(dbg & 1)) {
-        uint64_t rec[RW];
-        for (int t = 0; t < RW; ++t) rec[t] = (t < WK) ? s_hot_key[(size_t)tid * WK + (t < WK ? t : 0)] : 0ULL;
-        defer_append<RW>(pk, rec, s_hot_cnt[tid]);
-    }
-    for (int d = 32; d > 0; d >>= 1) added += __shfl_down(added, d, 64);
-    if (lane == 0) {
-        if (added) atomicAdd(&p.stats[ST_KMERS], added);
-        log_cnt[region] = min(fill, cap32);
-    }
-    for (uint32_t b = lane; b < hist_nb; b += 64) hist[(size_t)b * G + region] = my_hist[b];
-}
-
 // ---- the two-kernel scan for multi-limb keys (k > 32) -------------------------------------------------------
 // As strip_desc_kernel / walk_log_kernel.  What the walk of a strip needs of the text is its FIRST k-mer (WK limbs),
 // the 16 bases that enter behind it and the validity bits (the bases that leave are the first 16 of the k-mer): a
@@ -1245,7 +719,7 @@ __global__ __launch_bounds__(NT, 4) void strip_desc_wide_kernel(TableParams p, c
     const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
     const uint64_t lt = (1ULL << lane) - 1ULL;
 
-    // text loaded one tile ahead, as in scan_log_kernel
+    // text loaded one tile ahead, as in strip_desc_kernel
     uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
     bool cur_pnl = true;
     uint32_t cur_line = 0;

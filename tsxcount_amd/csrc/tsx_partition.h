@@ -3,15 +3,16 @@
 // Random 64-bit global atomics top out at ~17 G/s on MI355X whatever the
 // footprint (profiles/round1_atomics_ubench.txt), so for large inputs the table
 // is not updated in place.  Instead:
-//   scan_log_kernel / scan_log_wide_kernel  (tsx_kernels.h) write hashed keys to one log
-//                          region per wave and keep a level-1 histogram per region (no atomics)
+//   strip_desc_kernel + walk_part_kernel  strip descriptions, then the walk with every lane busy, fused with radix
+//                          level 1 (one-limb keys); or + walk_log_kernel / walk_log_wide_kernel (tsx_kernels.h): hashed
+//                          keys to one log region per wave + a level-1 histogram per region (no atomics)
 //   offsets_*_kernel       exclusive scan of the histograms -> exact write offsets
 //   partition_ring_kernel  x1 or x2: radix-scatters records by the high bits of their
 //                          home slot into one list per table segment, through LDS
 //                          ring staging and 128-B bursts
-//   build_segments_kernel  one workgroup per 2^S-slot segment: segment in LDS,
-//                          inserts with LDS atomics, streamed back once
-//                          (build_segments_wide_kernel: multi-limb keys and slots)
+//   build_segments_stream_kernel  one workgroup per 2^S-slot segment: segment in LDS, inserts with LDS
+//                          atomics from wave-level key streams, streamed back once
+//                          (build_segments_wide_stream_kernel: multi-limb keys and slots)
 //   overflow_insert_kernel, deferred_insert_kernel: what did not fit a list, inserted
 //                          like the atomic path would -- AFTER the build
 //   split_owner_kernel, hist_kernel, add_hashed_kernel: the sharded (multi-GPU) legs
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NT) void partition_ring_kernel(
     lds_barrier();
     // The source region r: a contiguous run of records (src_start/src_cnt, or src_cap apart), or -- src_pcnt
     // given -- src_np PIECES of at most src_pcap records each, piece g at ((r * src_np + g) * src_pcap) with
-    // src_pcnt[r * src_np + g] records (the sub-lists scan_part_kernel's workgroups keep per level-1 bucket);
+    // src_pcnt[r * src_np + g] records (the sub-lists walk_part_kernel's workgroups keep per level-1 bucket);
     // workgroup c of the region then takes pieces c, c + cpr, ... as one stream.
     const uint64_t n = src_pcnt ? 0 : (src_start ? (uint64_t)src_cnt[r] : min((uint64_t)src_cnt[r], src_cap));   // records
     const uint64_t region_first = src_pcnt ? 0 : (src_start ? (uint64_t)src_start[r] : (uint64_t)r * src_cap);
@@ -583,368 +584,16 @@ __global__ __launch_bounds__(NT) void partition_ring_kernel(
     }
 }
 
-// ---- scan fused with radix level 1 (one-limb keys, two-level split) -----------------------------------------
-// scan_log_kernel writes every key to a log that level 1 reads again: 12.9 GB and a 3 ms launch per 1e9 k-mers
-// for nothing but a histogram.  This kernel keeps the level-1 staging rings next to the scan: the keys of a
-// strip go straight into the ring of their level-1 bucket, bursts of 128 B leave for the workgroup's own
-// sub-list of that bucket (fixed capacity dst_cap, list (b, g) at ((b * G + g) * dst_cap), its size in
-// dst_cnt[b * G + g]; what does not fit: spill cache / overflow queue / deferred list, exactly as in level 2).
-// Level 2 reads a bucket as the G pieces the workgroups left (partition_ring_kernel, src_pcnt).
-// 512 threads, 8 KiB of text per tile, two workgroups per CU: the rings take 64 KiB, the LUT of the first
+// ---- the walk fused with radix level 1 (one-limb keys, two-level split): walk_part_kernel below --------------------
+// A key log that level 1 reads again costs 12.9 GB and a 3 ms launch per 1e9 k-mers for nothing but a histogram.
+// walk_part_kernel keeps the level-1 staging rings next to the walk: the keys of a strip go straight into the ring of
+// their level-1 bucket, bursts of 128 B leave for the workgroup's own sub-list of that bucket (fixed capacity dst_cap,
+// list (b, g) at ((b * G + g) * dst_cap), its size in dst_cnt[b * G + g]; what does not fit: spill cache / overflow
+// queue / deferred list, as in level 2).  Level 2 reads a bucket as the G pieces the workgroups left
+// (partition_ring_kernel, src_pcnt).  512 threads, two workgroups per CU: the rings take 64 KiB, the LUT of the first
 // window is the 4-bit-group one (2 KiB, 16 lookups per strip instead of 8) so that two workgroups fit.
-// A tile: classify -> line index -> strip masks, first window -> [8 rolls, append to rings, flush] x 2.
 constexpr int SP_NT = 512;
-constexpr int SP_TILE = SP_NT * 16;
 constexpr uint32_t SP_CAPBITS = 5;   // 32 words per ring: 15 may stay behind a flush, ~7 arrive per half strip
-
-__global__ __launch_bounds__(SP_NT, 4) void scan_part_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
-                                                            int head_open, const uint32_t *tile_line, uint64_t ntiles,
-                                                            int dbg, uint64_t *dst, uint64_t dst_cap,
-                                                            unsigned long long *dst_cnt, uint32_t nb, uint32_t shift,
-                                                            uint64_t *ovq_all, uint32_t *ovq_cnt, uint32_t ovq_cap) {
-    __shared__ uint64_t s_codes[(SP_TILE + HALO) / 32 + 2];
-    __shared__ uint64_t s_nl[(SP_TILE + HALO) / 64 + 3];
-    __shared__ uint64_t s_le[SP_TILE / 64];
-    __shared__ uint8_t s_lb[SP_TILE / 16];
-    __shared__ uint32_t s_wsum[SP_NT / 64];
-    constexpr int HOT_N = 8;
-    __shared__ uint64_t s_hot_key[(SP_NT / 64) * HOT_N];
-    __shared__ uint32_t s_hot_cnt[(SP_NT / 64) * HOT_N];
-    __shared__ uint64_t s_roll[64];
-    __shared__ uint64_t s_lut4[256];
-    __shared__ uint64_t s_homh[4];
-    __shared__ uint32_t s_njobs[2];
-    __shared__ uint32_t s_ovn;
-    __shared__ uint64_t s_ovk[OVF_N];
-    __shared__ uint32_t s_ovc[OVF_N];
-    extern __shared__ uint64_t s_part[];   // rings | flush descriptors | cursors | tails | heads | jobs
-    constexpr uint32_t CAP = 1u << SP_CAPBITS, cmask = CAP - 1;
-    uint64_t *s_stage = s_part;
-    unsigned long long *s_meta = reinterpret_cast<unsigned long long *>(s_part + ((size_t)nb << SP_CAPBITS));
-    // tail (low word: keys that have asked for a place) and head (high word: keys flushed) of a ring share one
-    // 64-bit word: the returning atomic that takes a place brings the head along, no second LDS read per key
-    unsigned long long *s_th = s_meta + nb;
-    uint32_t *s_cur = reinterpret_cast<uint32_t *>(s_th + nb);   // words written to the own sub-list of the bucket
-    uint32_t *s_job = s_cur + nb;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t G = gridDim.x, wg = blockIdx.x;
-    const uint32_t cap32 = (uint32_t)min(dst_cap, (uint64_t)0xFFFFFFF0u);
-    // word `at` of the own sub-list of bucket b: one 32 x 32 -> 64 multiply-add (list numbers and capacities fit 32 bits)
-    auto word_of = [&](uint32_t b, uint32_t at) -> uint64_t * { return dst + ((uint64_t)(b * G + wg) * (uint64_t)cap32 + at); };
-    if (tid < 64) s_roll[tid] = p.roll[tid];
-    if (tid < 256) s_lut4[tid] = p.roll[64 + tid];
-    if (tid < 4) {   // hashes of the four homopolymer k-mers, from the global copy of the LUT
-        const uint64_t x = (0x5555555555555555ULL * (uint64_t)tid) & p.top_mask;
-        uint64_t hh = 0;
-        for (int grp = 0; grp < 16; ++grp) hh ^= p.roll[64 + grp * 16 + ((x >> (4 * grp)) & 15u)];
-        s_homh[tid] = hh;
-    }
-    if (tid < (SP_NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
-    if (tid < 3) s_nl[(SP_TILE + HALO) / 64 + tid] = ~0ULL;
-    if (tid < 2) s_codes[(SP_TILE + HALO) / 32 + tid] = 0;
-    if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
-    if (tid < 2) s_njobs[tid] = 0;
-    if (tid == 0) s_ovn = 0;
-    for (uint32_t b = tid; b < nb; b += SP_NT) { s_cur[b] = 0; s_th[b] = 0; }
-    uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
-    unsigned long long added = 0;
-    uint32_t spilled = 0;
-    const uint32_t k = (uint32_t)p.k;
-    const uint32_t ngrp = (2u * k + 3u) / 4u;
-    const uint64_t start_lim = min(own_end, (n >= k) ? n - k + 1 : 0ULL);
-
-    const TableParams *pk = (const TableParams *)__builtin_amdgcn_kernarg_segment_ptr();
-    auto side_insert = [&](uint64_t hkey, uint64_t d) {
-        if (dbg & 1) return;
-        defer_append1(pk, hkey, d);
-    };
-    // a key that found its sub-list full: spill cache (a hot key hits it), overflow queue, deferred list
-    auto spill = [&](uint64_t key) {
-        ++spilled;
-        const uint64_t kk = key ^ OVF_SALT;
-        if (kk != 0) {
-            const uint32_t slot = (uint32_t)(mix64(key) >> 40) & (OVF_N - 1);
-            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&s_ovk[slot]), 0ULL,
-                                                     (unsigned long long)kk);
-            if (old == 0ULL || old == kk) { atomicAdd(&s_ovc[slot], 1u); return; }
-        }
-        if (ovq) {
-            const uint32_t at = atomicAdd(&s_ovn, 1u);
-            if (at < ovq_cap) { ovq[at] = key; return; }
-        }
-        side_insert(key, 1);
-    };
-    uint32_t round = 0;
-    // partition_ring_kernel's flush for one-word records and fixed-capacity lists: (A) one thread per list decides
-    // how many words leave (whole 128-B lines of the destination, or everything at the end), (B) an octet of lanes
-    // per list copies them.
-    auto flush = [&](bool all) {
-        const uint32_t par = round & 1u;
-        ++round;
-        if (tid == 0) s_njobs[par ^ 1u] = 0;
-        for (uint32_t b = tid; b < nb; b += SP_NT) {
-            const unsigned long long th = s_th[b];
-            const uint32_t head = (uint32_t)(th >> 32);
-            const uint32_t tail = min((uint32_t)th, head + CAP);   // arrivals past the ring went out directly
-            const uint32_t avail = tail - head;
-            const uint32_t at = s_cur[b];
-            const uint32_t end = (at + avail) & ~(uint32_t)(PART_FLUSH - 1);
-            const uint32_t nout = all ? avail : (end > at ? end - at : 0u);
-            s_meta[b] = ((unsigned long long)at << 16) | ((unsigned long long)(head & cmask) << 8) | nout;
-            s_th[b] = ((unsigned long long)(head + nout) << 32) | tail;
-            s_cur[b] = at + nout;
-            if (nout) s_job[atomicAdd(&s_njobs[par], 1u)] = b;
-        }
-        lds_barrier();
-        const uint32_t oct = tid >> 3, ol = tid & 7;
-        const uint32_t njobs = s_njobs[par];
-        // about 45 % of the lists have a line to send after a half strip: two jobs per octet and pass
-        constexpr int ITER = 2;
-        for (uint32_t j0 = 0; j0 < njobs; j0 += ITER * (SP_NT / 8)) {
-            unsigned long long meta[ITER];
-            uint32_t bj[ITER];
-            uint64_t k0[ITER], k1[ITER];
-#pragma unroll
-            for (int u = 0; u < ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (SP_NT / 8);
-                bj[u] = (j < njobs) ? s_job[j] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < ITER; ++u) {
-                const uint32_t j = j0 + oct + u * (SP_NT / 8);
-                meta[u] = (j < njobs) ? s_meta[bj[u]] : 0ULL;
-            }
-#pragma unroll
-            for (int u = 0; u < ITER; ++u) {
-                const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
-                const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
-                k0[u] = (ol < nout) ? ring[((hd + ol) ^ bj[u]) & cmask] : 0;     // (place ^ list: see the append)
-                k1[u] = (ol + 8 < nout) ? ring[((hd + ol + 8) ^ bj[u]) & cmask] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < ITER; ++u) {
-                const uint32_t nout = (uint32_t)meta[u] & 0xFFu, hd = ((uint32_t)meta[u] >> 8) & 0xFFu;
-                const uint32_t at = (uint32_t)(meta[u] >> 16);
-                const uint64_t *ring = s_stage + (bj[u] << SP_CAPBITS);
-                uint64_t *out = word_of(bj[u], at);
-                if (ol < nout) { if (at + ol < cap32) out[ol] = k0[u]; else spill(k0[u]); }
-                if (ol + 8 < nout) { if (at + ol + 8 < cap32) out[ol + 8] = k1[u]; else spill(k1[u]); }
-                if (nout > 16)
-                    for (uint32_t q = ol + 16; q < nout; q += 8) {
-                        const uint64_t w = ring[((hd + q) ^ bj[u]) & cmask];
-                        if (at + q < cap32) out[q] = w; else spill(w);
-                    }
-            }
-        }
-    };
-
-    // text of the tile: 16 bytes per lane and "the byte before them is a newline", loaded one tile ahead
-    uint4 cur = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au), hcur = cur;
-    bool cur_pnl = true;
-    uint32_t cur_line = 0;
-    if ((uint64_t)blockIdx.x < ntiles) {
-        const uint64_t off = (uint64_t)blockIdx.x * SP_TILE + (uint64_t)tid * 16;
-        cur_line = tile_line[(uint64_t)blockIdx.x * (SP_TILE / TILE)];
-        cur = load16(buf, off, n);
-        cur_pnl = prev_is_nl(buf, off, n, head_open);
-        if (tid < HALO / 16) hcur = load16(buf, (uint64_t)blockIdx.x * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
-    }
-    lds_barrier();
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t base = tile * SP_TILE;
-        {   // (the previous tile ended with a barrier behind its last flush; the first tile: the one above)
-            uint32_t nl, le, code;
-            classify16(cur, cur_pnl, nl, le, code);
-            reinterpret_cast<uint32_t *>(s_codes)[tid] = code;
-            reinterpret_cast<uint16_t *>(s_nl)[tid] = (uint16_t)nl;
-            reinterpret_cast<uint16_t *>(s_le)[tid] = (uint16_t)le;
-            if (tid < HALO / 16) {
-                uint32_t hnl, hle, hcode;
-                classify16(hcur, false, hnl, hle, hcode);
-                reinterpret_cast<uint32_t *>(s_codes)[SP_TILE / 16 + tid] = hcode;
-                reinterpret_cast<uint16_t *>(s_nl)[SP_TILE / 16 + tid] = (uint16_t)hnl;
-            }
-            const uint32_t c = __popc(le);
-            const uint32_t inc = wave_incl_scan(c);
-            if (lane == 63) s_wsum[wave] = inc;
-            lds_barrier();
-            uint32_t woff = cur_line;   // lines before the tile (the pre-pass counts per TILE bytes), loaded a tile ahead
-            for (uint32_t w = 0; w < wave; ++w) woff += s_wsum[w];
-            s_lb[tid] = (uint8_t)((woff + inc - c) & 3u);
-        }
-        {
-            const uint64_t nt = tile + gridDim.x;
-            if (nt < ntiles) {
-                const uint64_t off = nt * SP_TILE + (uint64_t)tid * 16;
-                cur_line = tile_line[nt * (SP_TILE / TILE)];
-                cur = load16(buf, off, n);
-                cur_pnl = prev_is_nl(buf, off, n, head_open);
-                if (tid < HALO / 16) hcur = load16(buf, nt * SP_TILE + SP_TILE + (uint64_t)tid * 16, n);
-            }
-        }
-        lds_barrier();
-
-        // ---- this lane's strip: start positions s .. s+15 of the tile (as in scan_log_kernel) -----------
-        const uint32_t s0 = tid * 16;
-        const uint32_t *codes32 = reinterpret_cast<const uint32_t *>(s_codes);
-        const uint32_t *nl32 = reinterpret_cast<const uint32_t *>(s_nl);
-        uint64_t m;
-        {
-            const uint32_t w = tid >> 1, sh = (tid & 1u) * 16u;
-            const uint32_t a0 = nl32[w], a1 = nl32[w + 1], a2 = nl32[w + 2];
-            m = (uint64_t)__funnelshift_r(a0, a1, sh) | ((uint64_t)__funnelshift_r(a1, a2, sh) << 32);
-        }
-        uint64_t r = m;
-        {
-            uint32_t span = 1;
-            while (span * 2 <= k) { r |= r >> span; span *= 2; }
-            if (span < k) r |= r >> (k - span);
-        }
-        const uint32_t e16 = reinterpret_cast<const uint16_t *>(s_le)[tid];
-        const uint32_t lb = s_lb[tid];
-        uint32_t c0 = e16 << 1; c0 ^= c0 << 1; c0 ^= c0 << 2; c0 ^= c0 << 4; c0 ^= c0 << 8;
-        uint32_t c1 = (e16 & c0) << 1; c1 ^= c1 << 1; c1 ^= c1 << 2; c1 ^= c1 << 4; c1 ^= c1 << 8;
-        const uint32_t l0 = (lb & 1u) ? 0xFFFFu : 0u, l1 = (lb & 2u) ? 0xFFFFu : 0u;
-        const uint32_t b0 = c0 ^ l0, b1 = c1 ^ l1 ^ (c0 & l0);
-        const uint64_t g0 = base + s0;
-        const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
-        const uint32_t nb1m = (p.line_mask & 2u) ? ~b1 : ~0u;
-        const uint32_t vm = ~(uint32_t)r & b0 & nb1m & ((1u << jmax) - 1u);
-        added += (unsigned long long)__popc(vm);
-        const uint32_t cw0 = codes32[tid], cw1 = codes32[tid + 1], cw2 = codes32[tid + 2];
-        const bool wave_has = __ballot(vm != 0u) != 0ULL;   // header, '+' and quality lines: nothing to walk
-        uint64_t h = 0;
-        uint32_t inc = 0, single = 0;
-        if (wave_has) {
-            const uint64_t lo = (uint64_t)cw0 | ((uint64_t)cw1 << 32), hi = cw2;
-            if (vm) {
-                const uint64_t x = lo & p.top_mask;
-                for (uint32_t grp = 0; grp < ngrp; ++grp) h ^= s_lut4[grp * 16u + ((uint32_t)(x >> (4u * grp)) & 15u)];
-            }
-            {
-                const uint32_t o = 2u * k, ws = o >> 5, sh = o & 31u;
-                const uint32_t w0 = (ws == 0u) ? cw0 : (ws == 1u) ? cw1 : cw2;
-                const uint32_t w1 = (ws == 0u) ? cw1 : (ws == 1u) ? cw2 : 0u;
-                inc = __funnelshift_r(w0, w1, sh);
-            }
-            uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
-            {
-                const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
-                uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
-                uint32_t span = 1;
-                while (span * 2 <= k - 1) {
-                    const uint32_t sh = 2u * span;
-                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
-                    rhi |= rhi >> sh;
-                    span *= 2;
-                }
-                if (span < k - 1) {
-                    const uint32_t sh = 2u * (k - 1 - span);
-                    rlo |= (rlo >> sh) | (rhi << (64u - sh));
-                }
-                uint32_t x = ~(uint32_t)rlo & 0x55555555u;
-                x = (x | (x >> 1)) & 0x33333333u;
-                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-                x = (x | (x >> 4)) & 0x00FF00FFu;
-                homm = (x | (x >> 8)) & 0xFFFFu;
-            }
-            const uint32_t hv = vm & homm;
-            single = vm & ~homm;
-            if (__ballot(hv != 0u)) {
-                for (uint32_t b = 0; b < 4; ++b) {
-                    uint32_t e = cw0 ^ (0x55555555u * b);
-                    uint32_t y = ~(e | (e >> 1)) & 0x55555555u;
-                    y = (y | (y >> 1)) & 0x33333333u;
-                    y = (y | (y >> 2)) & 0x0F0F0F0Fu;
-                    y = (y | (y >> 4)) & 0x00FF00FFu;
-                    y = (y | (y >> 8)) & 0xFFFFu;
-                    uint32_t tot = (uint32_t)__popc(hv & y);
-                    if (__ballot(tot != 0u) == 0ULL) continue;
-                    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
-                    if (lane == 0) {
-                        const uint64_t key = s_homh[b];
-                        uint64_t *hkey = s_hot_key + wave * HOT_N;
-                        uint32_t *hcnt = s_hot_cnt + wave * HOT_N;
-                        int at = -1;
-                        for (int q = 0; q < HOT_N; ++q)
-                            if (hcnt[q] && hkey[q] == key) { at = q; break; }
-                        if (at < 0)
-                            for (int q = 0; q < HOT_N; ++q)
-                                if (!hcnt[q]) { at = q; hkey[q] = key; break; }
-                        if (at >= 0 && (uint64_t)hcnt[at] + tot < 0xFFFFFFF0ULL) hcnt[at] += tot;
-                        else side_insert(key, tot);
-                    }
-                }
-            }
-        }
-        // ---- the strip in two halves of 8 positions: roll, append to the rings, flush ----------------------
-        for (uint32_t j0 = 0; j0 < 16; j0 += 8) {
-            const uint32_t s8 = (single >> j0) & 0xFFu;
-            if (wave_has) {
-                if (__ballot(s8 != 0u) == 0ULL) {   // nothing to append in this half: only roll on
-                    if (j0 == 0) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * j, 2u) << 2) |
-                                                 (__builtin_amdgcn_ubfe(inc, 2u * j, 2u) << 4);
-                            h = (h >> 2) ^ s_roll[idx];
-                        }
-                    }
-                } else {
-                    uint64_t hs[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        hs[j] = h;
-                        if (j0 + j < 15) {
-                            const uint32_t idx = ((uint32_t)h & 3u) | (__builtin_amdgcn_ubfe(cw0, 2u * (j0 + j), 2u) << 2) |
-                                                 (__builtin_amdgcn_ubfe(inc, 2u * (j0 + j), 2u) << 4);
-                            h = (h >> 2) ^ s_roll[idx];
-                        }
-                    }
-                    // ring places of all eight first (the returning LDS atomics are in flight together), then the keys
-                    uint32_t bq[8];
-                    unsigned long long sl[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        bq[j] = (uint32_t)(hs[j] >> shift) & (nb - 1);
-                        sl[j] = ((s8 >> j) & 1u) ? atomicAdd(&s_th[bq[j]], 1ULL) : 0ULL;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if ((s8 >> j) & 1u) {
-                            const uint32_t b = bq[j];
-                            if ((uint32_t)sl[j] - (uint32_t)(sl[j] >> 32) < CAP) {
-                                // place ^ list number: lanes that write the same place of different rings would
-                                // otherwise all hit the same pair of LDS banks (a ring is 32 words = all 64 banks)
-                                s_stage[(b << SP_CAPBITS) + (((uint32_t)sl[j] ^ b) & cmask)] = hs[j];
-                            } else {   // ring full: the next place of the list directly
-                                const uint32_t at = atomicAdd(&s_cur[b], 1u);
-                                if (at < cap32) *word_of(b, at) = hs[j];
-                                else spill(hs[j]);
-                            }
-                        }
-                    }
-                }
-            }
-            lds_barrier();
-            flush(false);
-            lds_barrier();
-        }
-    }
-    lds_barrier();
-    flush(true);
-    lds_barrier();
-    for (uint32_t b = tid; b < nb; b += SP_NT) dst_cnt[(uint64_t)b * G + wg] = min(s_cur[b], cap32);
-    if (tid < OVF_N && s_ovc[tid] && !(dbg & 1)) side_insert(s_ovk[tid] ^ OVF_SALT, s_ovc[tid]);
-    if (tid == 0 && ovq_cnt) ovq_cnt[blockIdx.x] = min(s_ovn, ovq_cap);
-    if (tid < (SP_NT / 64) * HOT_N && s_hot_cnt[tid]) side_insert(s_hot_key[tid], s_hot_cnt[tid]);
-    for (int d = 32; d > 0; d >>= 1) { added += __shfl_down(added, d, 64); spilled += __shfl_down(spilled, d, 64); }
-    if (lane == 0) {
-        if (added) atomicAdd(&p.stats[ST_KMERS], added);
-        if (spilled) atomicAdd(&p.stats[ST_FALLBACK], (unsigned long long)spilled);
-    }
-}
 
 // Descriptions of one text window, packed for the exchange of a sharded run: strip_desc_kernel leaves one region per
 // wave; desc_prefix_kernel (one workgroup) turns the region sizes into offsets, desc_pack_kernel copies the regions
@@ -979,9 +628,8 @@ __global__ __launch_bounds__(256) void desc_pack_kernel(const uint4 *desc, uint6
 
 // ---- walk_part_kernel: the second half of the two-kernel scan (strip_desc_kernel, tsx_kernels.h) -----------
 // Reads strip descriptions (48 bases as 2-bit codes + 16 validity bits), ONE PER LANE, every lane busy: first
-// window by the 4-bit-group LUT, 15 rolls, the keys into the level-1 rings, bursts to the workgroup's sub-lists --
-// the walk and ring parts of scan_part_kernel without its tile front end.  A batch = 512 strips = up to 8192 keys:
-// four flushes per batch (one per four positions), the same keys per flush as scan_part_kernel.  Workgroup g takes
+// window by the 4-bit-group LUT, 15 rolls, the keys into the level-1 rings, bursts to the workgroup's sub-lists.
+// A batch = 512 strips = up to 8192 keys: four flushes per batch (one per four positions).  Workgroup g takes
 // the descriptor regions g, g + G, ... (a region = what one wave of strip_desc_kernel wrote).
 template <int NT>   // 512 threads, two workgroups per CU (up to 256 level-1 lists); 1024 threads where 512 lists leave room for one
 __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
@@ -1550,134 +1198,9 @@ __global__ __launch_bounds__(PART_NT) void add_hashed_kernel(TableParams p, cons
     }
 }
 
-// One workgroup builds one segment: slots [seg << S, (seg+1) << S) live in LDS
-// while the segment's key list is inserted with LDS atomics (same slot format,
-// same probe sequence as insert_key), then go back to HBM in one sweep.
-// Segments that already hold data (seg_dirty) are loaded first; untouched
-// segments with an empty list are skipped -- unless the table is `fresh` (cleared but not
-// zeroed, tsx_hip_clear): then nothing is loaded and a segment without keys is written as zeros,
-// so that after the build every slot of the table has been written exactly once.
-__global__ __launch_bounds__(1024) void build_segments_kernel(TableParams p, const uint64_t *lists,
-                                                              const unsigned long long *list_start,
-                                                              const unsigned long long *list_cnt,
-                                                              uint64_t list_cap, uint32_t pieces, uint32_t nseg,
-                                                              int dbg, int fresh) {
-    extern __shared__ uint64_t s_seg[];  // 2^S slots
-    __shared__ uint32_t s_pn[8];         // sizes of the segment's sub-lists
-    const uint32_t nslots = 1u << p.S;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        // a segment's keys: one packed run (list_start) or up to 8 sub-lists of list_cap
-        uint64_t n = 0;
-        const uint64_t *in0;
-        uint32_t npieces;
-        if (list_start) {
-            n = (uint64_t)list_cnt[seg];
-            in0 = lists + (uint64_t)list_start[seg];
-            npieces = 1;
-        } else {
-            for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
-            in0 = lists + (uint64_t)seg * pieces * list_cap;
-            npieces = pieces;
-        }
-        uint64_t *slots = p.table + ((uint64_t)seg << p.S);
-        if (n == 0) {
-            if (fresh) {   // nothing to insert, but the stale slots must go
-                for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
-                    *reinterpret_cast<uint4 *>(&slots[i]) = make_uint4(0, 0, 0, 0);
-                if (tid == 0) p.seg_dirty[seg] = 0;
-            }
-            continue;
-        }
-        const bool dirty = !fresh && p.seg_dirty[seg] != 0;
-        lds_barrier();  // previous segment fully written out
-        if (list_start) { if (tid == 0) s_pn[0] = (uint32_t)n; }
-        else if (tid < pieces) s_pn[tid] = (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + tid], list_cap);
-        if (dirty) {
-            for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
-                *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
-        } else {
-            for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
-                *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
-        }
-        lds_barrier();
-        const uint64_t one = 1ULL << p.cshift;
-        // Every lane streams its own keys: one probe per loop round, and a lane that has
-        // placed its key moves straight on to its next one, so the wave stays full until
-        // the lists run dry instead of idling on its longest probe chain.  The loop is
-        // VALU-issue bound (measured: same time with 10 or 16 waves per CU), so it is kept
-        // short: the probe position advances by addition (q_i = q_{i-1} + i), the slot
-        // image of the key is built once per key, and the read cursor is a plain pointer --
-        // with several sub-lists the workgroup splits into one thread group per sub-list.
-        // BUILD_AHEAD keys per lane are in flight from HBM.
-        constexpr int BUILD_AHEAD = 4;
-        uint32_t grp = 0, gl = tid, gstride = nt;
-        if (npieces > 1) {
-            gstride = nt / npieces;
-            grp = tid / gstride;
-            gl = tid - grp * gstride;
-        }
-        const uint32_t mine = (grp < npieces) ? s_pn[grp] : 0u;
-        const uint64_t *ptr = in0 + (uint64_t)grp * list_cap + gl;
-        uint32_t left = (gl < mine) ? (mine - gl + gstride - 1) / gstride : 0;   // keys this lane inserts
-        uint32_t ahead = left;                                                    // keys not fetched yet
-        auto fetch_next = [&]() -> uint64_t {
-            const uint64_t v = ahead ? *ptr : 0ULL;
-            ahead -= ahead ? 1u : 0u;
-            ptr += gstride;
-            return v;
-        };
-        uint64_t cur = fetch_next();
-        uint64_t fifo[BUILD_AHEAD];
-#pragma unroll
-        for (int u = 0; u < BUILD_AHEAD; ++u) fifo[u] = fetch_next();
-        bool live = (left > 0) && !(dbg & 2);
-        const uint32_t smask = (uint32_t)p.seg_mask;
-        const uint64_t k0mask = p.k0mask;
-        const uint32_t maxr = p.max_reprobes;
-        uint32_t i = 1;
-        uint32_t q = ((uint32_t)cur + 1u) & smask;                        // q_1 = q_0 + 1
-        uint64_t e0 = ((cur >> p.lg) << p.R) & k0mask;                    // split_key for WK = 1
-        while (live) {
-            const uint64_t key0 = e0 | i;
-            const unsigned long long old =
-                atomicCAS(reinterpret_cast<unsigned long long *>(&s_seg[q]), 0ULL, (unsigned long long)(key0 | one));
-            bool placed = (old == 0ULL);
-            if (!placed && (old & k0mask) == key0) {
-                const unsigned long long prev =
-                    atomicAdd(reinterpret_cast<unsigned long long *>(&s_seg[q]), (unsigned long long)one);
-                const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
-                if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
-                placed = true;
-            }
-            if (!placed && i >= maxr) {
-                atomicAdd(&p.stats[ST_FAIL], 1ULL);
-                placed = true;
-            }
-            ++i;
-            q = (q + i) & smask;
-            if (placed) {
-                live = --left > 0;
-                cur = fifo[0];
-#pragma unroll
-                for (int u = 0; u + 1 < BUILD_AHEAD; ++u) fifo[u] = fifo[u + 1];
-                fifo[BUILD_AHEAD - 1] = fetch_next();
-                i = 1;
-                q = ((uint32_t)cur + 1u) & smask;
-                e0 = ((cur >> p.lg) << p.R) & k0mask;
-            }
-        }
-        lds_barrier();
-        if (!(dbg & 4))
-            for (uint32_t i = tid * 2; i < nslots; i += nt * 2)
-                *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);
-        if (tid == 0) p.seg_dirty[seg] = 1;
-    }
-}
-
-// ---- build, second form (one-limb keys and slots): wave-level key streams --------------------------
-// build_segments_kernel above gives every LANE a private stream of keys with a register FIFO of loads in
-// flight.  Its disassembly shows what that costs: the FIFO advances by register moves, a move of a load's
+// ---- the segment build (one-limb keys and slots): wave-level key streams --------------------------
+// Round 1's form gave every LANE a private stream of keys with a register FIFO of loads in
+// flight.  Its disassembly showed what that costs: the FIFO advances by register moves, a move of a load's
 // destination needs that load finished, the wave's load counter is in order -- so every round in which ANY
 // lane places a key (nearly all of them) waits for the load issued one round earlier: the loop runs at one
 // HBM latency per round (~1000 cycles for ~40 instructions), and a lane's 12 keys take 22 rounds on
@@ -1962,147 +1485,9 @@ __global__ __launch_bounds__(1024) void build_segments_stream_kernel(TableParams
     }
 }
 
-// The same for multi-limb keys and/or multi-limb slots (k > 32, or wide counters): records of RW words,
-// slots of W words in LDS (AoS, like the table).  Limb 0 is claimed by a 64-bit LDS CAS with the LOCK bit
-// set, the claimant writes limbs 1..W-1 and then stores limb 0 without LOCK -- the protocol of insert_key
-// with LDS operations; a lane whose limb-0 key bits match a locked slot looks again in the next round (the
-// claimant, possibly a lane of the same wave, has published by then: the loop has no early exit).
-template <int WK>
-__global__ __launch_bounds__(1024) void build_segments_wide_kernel(TableParams p, const uint64_t *lists,
-                                                                   const unsigned long long *list_start,
-                                                                   const unsigned long long *list_cnt,
-                                                                   uint64_t list_cap, uint32_t pieces, uint32_t nseg,
-                                                                   int dbg, int fresh) {
-    constexpr int RW = RecWords<WK>::value;
-    extern __shared__ uint64_t s_seg[];  // 2^S slots of W words
-    __shared__ uint32_t s_pn[8];
-    const uint32_t W = (uint32_t)p.W;
-    const uint32_t nwords = (1u << p.S) * W;
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    for (uint32_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-        uint64_t n = 0;
-        const uint64_t *in0;
-        uint32_t npieces;
-        if (list_start) {
-            n = (uint64_t)list_cnt[seg];
-            in0 = lists + (uint64_t)list_start[seg] * RW;
-            npieces = 1;
-        } else {
-            for (uint32_t c = 0; c < pieces; ++c) n += min((uint64_t)list_cnt[(uint64_t)seg * pieces + c], list_cap);
-            in0 = lists + (uint64_t)seg * pieces * list_cap * RW;
-            npieces = pieces;
-        }
-        uint64_t *slots = p.table + ((uint64_t)seg << p.S) * W;
-        if (n == 0) {
-            if (fresh) {
-                for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
-                    *reinterpret_cast<uint4 *>(&slots[i]) = make_uint4(0, 0, 0, 0);
-                if (tid == 0) p.seg_dirty[seg] = 0;
-            }
-            continue;
-        }
-        const bool dirty = !fresh && p.seg_dirty[seg] != 0;
-        lds_barrier();
-        if (list_start) { if (tid == 0) s_pn[0] = (uint32_t)n; }
-        else if (tid < pieces) s_pn[tid] = (uint32_t)min((uint64_t)list_cnt[(uint64_t)seg * pieces + tid], list_cap);
-        if (dirty) {
-            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
-                *reinterpret_cast<uint4 *>(&s_seg[i]) = *reinterpret_cast<const uint4 *>(&slots[i]);
-        } else {
-            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
-                *reinterpret_cast<uint4 *>(&s_seg[i]) = make_uint4(0, 0, 0, 0);
-        }
-        lds_barrier();
-        const uint64_t one = 1ULL << p.cshift;
-        uint32_t grp = 0, gl = tid, gstride = nt;
-        if (npieces > 1) {
-            gstride = nt / npieces;
-            grp = tid / gstride;
-            gl = tid - grp * gstride;
-        }
-        const uint32_t mine = (grp < npieces) ? s_pn[grp] : 0u;
-        const uint64_t *ptr = in0 + ((uint64_t)grp * list_cap + gl) * RW;
-        uint32_t left = (gl < mine) ? (mine - gl + gstride - 1) / gstride : 0;
-        const uint32_t smask = (uint32_t)p.seg_mask;
-        const uint64_t k0mask = p.k0mask, lock = p.lock_bit;
-        const uint32_t maxr = p.max_reprobes;
-        bool live = (left > 0) && !(dbg & 2);
-        // the next record is in flight while the current one probes
-        uint64_t nxt[RW];
-        if (left > 0) load_rec<RW>(ptr, nxt);
-        else {
-#pragma unroll
-            for (int t = 0; t < RW; ++t) nxt[t] = 0;
-        }
-        uint64_t e0 = 0, hi[4] = {0, 0, 0, 0};
-        uint32_t i = 1, q = 0, spins = 0;
-        bool fresh_key = true;
-        while (live) {
-            if (fresh_key) {
-                uint64_t h[WK], pos0;
-#pragma unroll
-                for (int t = 0; t < WK; ++t) h[t] = nxt[t];
-                split_key<WK>(p, h, pos0, e0, hi);
-                i = 1;
-                q = ((uint32_t)pos0 + 1u) & smask;
-                ptr += (uint64_t)gstride * RW;
-                if (left > 1) load_rec<RW>(ptr, nxt);
-                fresh_key = false;
-            }
-            unsigned long long *slot = reinterpret_cast<unsigned long long *>(&s_seg[(size_t)q * W]);
-            const uint64_t key0 = e0 | i;
-            const unsigned long long old = atomicCAS(slot, 0ULL, (unsigned long long)(key0 | lock | one));
-            bool placed = false, next = false;
-            if (old == 0ULL) {
-                if (W > 1) {
-                    for (uint32_t t = 1; t < W; ++t) slot[t] = hi[t - 1];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __hip_atomic_store(slot, (unsigned long long)(key0 | one), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                placed = true;
-            } else if ((old & k0mask) != key0) {
-                next = true;
-            } else if (W > 1 && (old & lock)) {
-                // claimed, limbs not published yet: probe the same slot again in the next round (bounded: a
-                // lock that never clears must not hang the chip -- it is reported through ST_LOCKTO)
-                if (++spins > (1u << 20)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); spins = 0; next = true; }
-            } else {
-                bool same = true;
-                if (W > 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    for (uint32_t t = 1; t < W; ++t) same &= (slot[t] == hi[t - 1]);
-                }
-                if (same) {
-                    const unsigned long long prev = atomicAdd(slot, (unsigned long long)one);
-                    const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
-                    if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
-                    placed = true;
-                } else {
-                    next = true;
-                }
-            }
-            if (next) {
-                if (i >= maxr) { atomicAdd(&p.stats[ST_FAIL], 1ULL); placed = true; }
-                ++i;
-                q = (q + i) & smask;
-            }
-            if (placed) {
-                live = --left > 0;
-                fresh_key = true;
-                spins = 0;
-            }
-        }
-        lds_barrier();
-        if (!(dbg & 4))
-            for (uint32_t i = tid * 2; i < nwords; i += nt * 2)
-                *reinterpret_cast<uint4 *>(&slots[i]) = *reinterpret_cast<const uint4 *>(&s_seg[i]);
-        if (tid == 0) p.seg_dirty[seg] = 1;
-    }
-}
-
 // ---- the wave-stream build for multi-limb keys and slots ------------------------------------------------
-// build_segments_wide_kernel above has the disease build_segments_kernel had (a per-lane load in flight that
-// the wave waits for in nearly every round).  Same cure as build_segments_stream_kernel: a wave owns a stream of
+// The same form as build_segments_stream_kernel (the per-lane form of round 2 had a load in flight that the wave
+// waited for in nearly every round): a wave owns a stream of
 // batches of 64 records, loaded up front into registers (BKW batches of RW words per wave and pass); the batch
 // being consumed sits in the wave's own slice of LDS behind the segment (64 records; a round hands out keys of
 // that one batch only), a lane that has placed its key takes the next record of it.  The slot protocol is the
@@ -2264,26 +1649,23 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
                     if (blen == 0) break;   // stream dry and every key placed
                     continue;
                 }
-                // ---- one probe for every lane that holds a key
+                // ---- one probe for every lane that holds a key.  No && and no else-if chain: every short-circuit is a branch,
+                // and the loop is bound by instruction issue (the same cure as in build_segments_stream_kernel).
                 if (i != 0u) {
                     unsigned long long *slot = reinterpret_cast<unsigned long long *>(&s_seg[(size_t)q * W]);
                     const uint64_t key0 = e0 | i;
                     const unsigned long long old = atomicCAS(slot, 0ULL, (unsigned long long)(key0 | lock | one));
-                    bool placed = false, next = false;
-                    if (old == 0ULL) {
-                        if (W > 1) {
-                            for (uint32_t t = 1; t < W; ++t) slot[t] = hi[t - 1];
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                            __hip_atomic_store(slot, (unsigned long long)(key0 | one), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        placed = true;
-                    } else if ((old & k0mask) != key0) {
-                        next = true;
-                    } else if (W > 1 && (old & lock)) {
-                        // claimed, limbs not published yet: probe the same slot again in the next round (bounded)
-                        if (++spins > (1u << 20)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); spins = 0; next = true; }
-                    } else {
-                        bool same = true;
+                    const bool claimed = (old == 0ULL);
+                    const bool mine0 = ((old & k0mask) == key0);           // limb-0 key bits equal (never so when claimed: i >= 1)
+                    const bool locked = (old & lock) != 0ULL;
+                    if (claimed && W > 1) {   // publish the other limbs, then the unlocked limb 0
+                        for (uint32_t t = 1; t < W; ++t) slot[t] = hi[t - 1];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __hip_atomic_store(slot, (unsigned long long)(key0 | one), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    bool same = false;
+                    if (mine0 & !locked) {    // (duplicates are rare on most inputs: this block is skipped by most waves)
+                        same = true;
                         if (W > 1) {
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                             for (uint32_t t = 1; t < W; ++t) same &= (slot[t] == hi[t - 1]);
@@ -2292,17 +1674,17 @@ __global__ __launch_bounds__(1024) void build_segments_wide_stream_kernel(TableP
                             const unsigned long long prev = atomicAdd(slot, (unsigned long long)one);
                             const uint64_t carry = ((prev >> p.cshift) + 1) >> p.C;
                             if (carry) sec_add(p, ((uint64_t)seg << p.S) | q, carry);
-                            placed = true;
-                        } else {
-                            next = true;
                         }
                     }
-                    if (next) {
-                        if (i >= maxr) { atomicAdd(&p.stats[ST_FAIL], 1ULL); placed = true; }
-                        ++i;
-                        q = (q + i) & smask;
+                    bool next = !claimed & !same & !(mine0 & locked);
+                    if (mine0 & locked) {     // claimed by another lane, limbs not published yet: the same slot again next round (bounded)
+                        if (++spins > (1u << 20)) { atomicAdd(&p.stats[ST_LOCKTO], 1ULL); spins = 0; next = true; }
                     }
-                    if (placed) i = 0u;
+                    bool placed = claimed | same;
+                    if (next & (i >= maxr)) { atomicAdd(&p.stats[ST_FAIL], 1ULL); placed = true; }
+                    const uint32_t i1 = i + (next ? 1u : 0u);
+                    q = next ? ((q + i1) & smask) : q;
+                    i = placed ? 0u : i1;
                 }
             }
         }

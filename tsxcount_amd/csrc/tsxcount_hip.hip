@@ -32,7 +32,7 @@ static thread_local std::string g_last_error;
         }                                                                                \
     } while (0)
 
-static int scan_wg_per_cu() {  // scan_log_kernel workgroups per CU: 5 are resident (88 VGPRs, 28 KiB LDS); 4: +0.35 ms
+static int scan_wg_per_cu() {  // walk_log_kernel workgroups per CU
     static int v = 0;
     if (!v) { v = 5; if (const char *e = getenv("TSX_HIP_SCAN_WGS")) v = std::min(16, std::max(1, atoi(e))); }
     return v;
@@ -506,7 +506,7 @@ extern "C" int tsx_hip_create_shard(tsx_hip_map **out, int k, int l, int storage
         const void *src = (p.wk == 1) ? (const void *)m->roll : (const void *)m->roll_wide.data();
         const size_t bytes = (size_t)64 * p.wk * 8;
         // one-limb keys: the same mapping as a LUT by 4-bit groups (16 x 16 entries = 2 KiB) behind the roll
-        // table -- scan_part_kernel has no LDS to spare for the 8-bit-group LUT (16 KiB)
+        // table -- walk_part_kernel has no LDS to spare for the 8-bit-group LUT (16 KiB)
         std::vector<uint64_t> lut4;
         if (p.wk == 1) {
             lut4.assign(256, 0);
@@ -669,7 +669,7 @@ struct PartPlan {
     unsigned long long *c_log, *c_rstart, *c_bstart, *c_bcnt, *c_seg, *d_offs;
     uint32_t *d_hist;
     size_t cnt_need;
-    // scan fused with level 1 (scan_part_kernel): G1 workgroups, each with a sub-list of cap1 records per level-1
+    // walk fused with level 1 (walk_part_kernel): G1 workgroups, each with a sub-list of cap1 records per level-1
     // bucket in buffer 1 (list (b, g) at (b * G1 + g) * cap1), sizes in c_l1[b * G1 + g]
     bool fused;
     uint32_t G1;
@@ -820,23 +820,19 @@ static int plan_partition(tsx_hip_map *m, uint64_t maxrec, int g, bool own_log, 
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2, RING_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4, RING_NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<1, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<2, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIP_TRY(hipFuncSetAttribute((const void *)partition_ring_kernel<4, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_stream_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
-        HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
         HIP_TRY(hipFuncSetAttribute((const void *)build_segments_wide_stream_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, seg + (32 << 10)));
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_part_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel<SP_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
         HIP_TRY(hipFuncSetAttribute((const void *)walk_part_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
-        HIP_TRY(hipFuncSetAttribute((const void *)scan_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)walk_log_wide_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         HIP_TRY(hipFuncSetAttribute((const void *)walk_log_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
         m->attr_done = true;
@@ -892,28 +888,31 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     hipLaunchKernelGGL(offsets_finish_kernel, dim3(1), dim3(1024), 0, st, pl.nb1, pl.c_bstart, pl.c_bcnt);
     {   // level 1: every region -> packed array ordered by the top b1 bits of the home slot
         const uint32_t bits = ring_bits(pl.nb1);
-        DISPATCH_RW(rw, hipLaunchKernelGGL((partition_ring_kernel<RWV>), dim3(pl.g), dim3(RING_NT), part_lds(pl.nb1, bits), st,
-                           pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,
-                           pl.buf1, (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,
-                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,
-                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0,
-                           0, (unsigned long long *)nullptr, 0u, 0u, 0, 0u, (const uint32_t *)nullptr));
+#define TSX_LEVEL1(RWV, NTV)                                                                                                   \
+        hipLaunchKernelGGL((partition_ring_kernel<RWV, NTV>), dim3(pl.g), dim3(NTV), part_lds(pl.nb1, bits), st,                 \
+                           pp, src, region_start, (const unsigned long long *)pl.c_log, src_cap, (uint32_t)pl.g, 1u,             \
+                           pl.buf1, (const unsigned long long *)pl.d_offs, (const unsigned long long *)pl.c_bstart,              \
+                           (unsigned long long *)nullptr, (uint64_t)0, pl.nb1, (uint32_t)(p.l - pl.b1), bits, m->dbg,            \
+                           (uint64_t *)nullptr, (uint32_t *)nullptr, 0u, (const unsigned long long *)nullptr, 0u, (uint64_t)0,   \
+                           0, (unsigned long long *)nullptr, 0u, 0u, 0, 0u, (const uint32_t *)nullptr)
+        // (512 lists: the rings leave room for one workgroup per CU -- 1024 threads then, 16 waves either way)
+        if (part_lds(pl.nb1, bits) > ((size_t)80 << 10)) { DISPATCH_RW(rw, TSX_LEVEL1(RWV, 1024)); }
+        else { DISPATCH_RW(rw, TSX_LEVEL1(RWV, RING_NT)); }
+#undef TSX_LEVEL1
         HIP_TRY(hipGetLastError());
     }
-    }   // (fused: scan_part_kernel has left the level-1 sub-lists in buffer 1)
+    }   // (fused: walk_part_kernel has left the level-1 sub-lists in buffer 1)
     if (ev) HIP_TRY(hipEventRecord(ev[4], st));
     const uint64_t *lists = pl.buf1;
     const unsigned long long *lists_start = pl.c_bstart, *lists_cnt = pl.c_bcnt;
     uint64_t lists_cap = 0;
     uint32_t pieces = 1;
     uint32_t nq2 = 0;
-    static int build_v = -1;   // TSX_HIP_BUILD_V=1: the per-lane FIFO form (kept for A/B runs)
-    if (build_v < 0) { const char *e = getenv("TSX_HIP_BUILD_V"); build_v = e ? atoi(e) : 2; }
     // level 2 leaves PRE-FORMATTED records (format_record, tsx_partition.h) where the stream build of one-limb keys and
     // slots reads them and the fields fit: slot image in bits [0, R + F), first probe position above (TSX_HIP_BUILD_PRE=0: raw keys)
     static int pre_ok = -1;
     if (pre_ok < 0) { const char *e = getenv("TSX_HIP_BUILD_PRE"); pre_ok = e ? atoi(e) : 1; }
-    const int pre = (pre_ok && pl.b2 && p.wk == 1 && p.W == 1 && build_v == 2 && !m->dbg && p.R + p.F >= 32 && p.R + p.F + p.S <= 64) ? 1 : 0;
+    const int pre = (pre_ok && pl.b2 && p.wk == 1 && p.W == 1 && !m->dbg && p.R + p.F >= 32 && p.R + p.F + p.S <= 64) ? 1 : 0;
     if (pl.b2) {  // level 2: cpr2 workgroups per level-1 bucket, each with its own sub-list per segment
         const uint32_t bits = ring_bits(pl.nb2);
         nq2 = pl.nb1 * pl.cpr2;   // one overflow queue per workgroup (the fused scan's queues follow them)
@@ -948,9 +947,8 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                            pl.nb2, (uint32_t)p.S, BITS, m->dbg, m->d_ovq, m->d_ovq_cnt, OVQ_CAP,                                 \
                            (const unsigned long long *)(pl.fused ? pl.c_l1 : nullptr), pl.G1, pl.cap1, 0,                       \
                            (unsigned long long *)nullptr, 0u, 0u, pre, dch, (const uint32_t *)d_skew)
-        if (rw == 1 && part_lds(pl.nb2, bits) > ((size_t)80 << 10)) {
-            TSX_LEVEL2(1, 1024, false, 5u);
-            TSX_LEVEL2(1, 1024, true, 5u);
+        if (part_lds(pl.nb2, bits) > ((size_t)80 << 10)) {
+            DISPATCH_RW(rw, TSX_LEVEL2(RWV, 1024, false, bits); TSX_LEVEL2(RWV, 1024, true, bits));
         } else {
             DISPATCH_RW(rw, TSX_LEVEL2(RWV, RING_NT, false, bits); TSX_LEVEL2(RWV, RING_NT, true, bits));
         }
@@ -962,12 +960,10 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
     const int fresh = m->fresh ? 1 : 0;
     if (!(m->dbg & 64)) {  // ablation: bit 6 skips the build (partition timing experiments)
         const int gb = (int)std::min<uint32_t>(pl.nseg, (uint32_t)m->cus * 16);
-        int bnt = 1024;
-        if (const char *e = getenv("TSX_HIP_BUILD_NT")) bnt = std::min(1024, std::max(64, atoi(e) & ~63));
         const size_t seg_bytes = ((size_t)8 << p.S) * p.W;
         static int build_la = -1;   // TSX_HIP_BUILD_LOOKAHEAD=0|1: the tail's look-ahead over the next probe positions
         if (build_la < 0) { const char *e = getenv("TSX_HIP_BUILD_LOOKAHEAD"); build_la = e ? atoi(e) : 1; }
-        if (p.wk == 1 && p.W == 1 && build_v == 2) {
+        if (p.wk == 1 && p.W == 1) {
             if (m->dbg)   // the instance with the ablation / diagnostic switches compiled in
                 hipLaunchKernelGGL((build_segments_stream_kernel<true, false>), dim3(gb), dim3(1024), seg_bytes + (32 << 10), st, pp,
                                    lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh, build_la);
@@ -983,17 +979,11 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                     hipLaunchKernelGGL((build_segments_stream_kernel<false, false>), dim3(gb), dim3(snt), seg_bytes + (size_t)(snt / 64) * 2048, st, pp,
                                        lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_la);
             }
-        } else if (p.wk == 1 && p.W == 1) {
-            hipLaunchKernelGGL(build_segments_kernel, dim3(gb), dim3(bnt), seg_bytes, st, pp, lists, lists_start,
-                               lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh);
-        } else if (build_v == 2) {   // multi-limb keys and / or slots: wave streams too (64 records of LDS per wave behind the segment)
+        } else {   // multi-limb keys and / or slots: wave streams too (64 records of LDS per wave behind the segment)
             const size_t ring_bytes = (size_t)16 * 64 * 8 * rw;
             DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_stream_kernel<WKV>), dim3(gb), dim3(1024),
                                               seg_bytes + ring_bytes, st, pp, lists, lists_start, lists_cnt, lists_cap, pieces,
                                               pl.nseg, fresh));
-        } else {
-            DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_kernel<WKV>), dim3(gb), dim3(bnt), seg_bytes, st, pp,
-                                              lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, m->dbg, fresh));
         }
         HIP_TRY(hipGetLastError());
         m->fresh = false;   // every segment has been written: built, or zeroed
@@ -1119,21 +1109,17 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
     const uint64_t maxrec = (p.line_mask == 3 ? own_end / 2 : own_end) + 65536;
     const uint32_t nown = 1u << (p.lg - p.l);
     // the scan kernels of this path keep one log region per WAVE
-    const char *scan2_env = getenv("TSX_HIP_SCAN2");   // 0: scan_log_kernel (one kernel) where the keys go to a log
-    const bool scan2 = !scan2_env || atoi(scan2_env) != 0;
-    // workgroups per CU of the kernel that writes the key log: scan_log_wide_kernel 2 (LDS, registers); the walk
-    // kernels of the two-kernel form carry no tile state: 6 for two-limb keys, 3 above (LUT of up to 32 KiB)
-    const int scan_wgs = (p.wk == 1) ? SCAN_WG_PER_CU : (scan2 ? (p.wk == 2 ? 6 : 3) : 2);
+    // workgroups per CU of the walk that writes the key log (it carries no tile state): 6 for two-limb keys, 3 above
+    // (LUT of up to 32 KiB)
+    const int scan_wgs = (p.wk == 1) ? SCAN_WG_PER_CU : (p.wk == 2 ? 6 : 3);
     const int gs = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * scan_wgs);
     const int greg = gs * (NT / 64);
     PartPlan pl;
-    // scan fused with radix level 1 (TSX_HIP_FUSE=0: the key log + separate level 1): local runs, one-limb keys
-    // 2 (default): strip descriptions + walk (two kernels), 1: scan_part_kernel (one), 0: key log + separate level 1.
-    // Read per call: the tests run all forms in one process.
+    // The walk fused with radix level 1 (local runs, one-limb keys, two radix levels); TSX_HIP_FUSE=0: the key log +
+    // a separate level 1 (what sharded scans and one-level tables take).  Read per call: the tests run both in one process.
     const char *fuse_env = getenv("TSX_HIP_FUSE");
-    const int fuse = fuse_env ? atoi(fuse_env) : 2;
-    const uint64_t ntiles_sp = (own_end + SP_TILE - 1) / SP_TILE;
-    const int g_sp = (int)std::min<uint64_t>(ntiles_sp, (uint64_t)m->cus * 2);
+    const int fuse = (fuse_env && atoi(fuse_env) == 0) ? 0 : 2;
+    const int g_sp = (int)std::min<uint64_t>((own_end + 8191) / 8192, (uint64_t)m->cus * 2);   // walk workgroups
     // strip_desc_kernel: 52 VGPRs, 2.4 KiB of LDS -- eight workgroups per CU (five: 3.9 ms for both kernels, eight: 3.7)
     static const int desc_wgs = getenv("TSX_HIP_DESC_WGS") ? std::min(16, std::max(1, atoi(getenv("TSX_HIP_DESC_WGS")))) : 8;
     const int gd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * desc_wgs), gdreg = gd * (NT / 64);
@@ -1161,7 +1147,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
         if (rc != TSX_HIP_OK) return rc;
         const size_t lds = (size_t)pl.nb1 * (((size_t)8 << SP_CAPBITS) + 8 + 8 + 4 + 4);   // ring, flush descriptor, tail|head, cursor, job
-        if (fuse == 2) {
+        {
             // two kernels: strip descriptions (16 B per strip with a k-mer start, one region per wave, in buffer 0 --
             // level 2 overwrites it later), then the walk with every lane busy
             // all keys stay on this GPU: a ring flush per quarter strip (TSX_HIP_WALK_FLUSHQ=2|4: experiments)
@@ -1186,12 +1172,8 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
                                    (const unsigned long long *)pl.c_log, (uint32_t)gdreg, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                                    (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP,
                                    (uint64_t)0, 0u, pl.G1, 0, (unsigned long long *)nullptr, lng, local_fq);
-        } else {
-            hipLaunchKernelGGL(scan_part_kernel, dim3(pl.G1), dim3(SP_NT), lds, st, pp, d_text, n, own_end, head_open,
-                               (const uint32_t *)m->d_tile, ntiles_sp, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
-                               (uint32_t)(p.l - pl.b1), m->d_ovq + (size_t)nq2 * OVQ_CAP, m->d_ovq_cnt + nq2, OVQ_CAP);
         }
-    } else if (p.wk == 1 && scan2) {
+    } else if (p.wk == 1) {
         // key log form (sharded scans, one-level tables), the scan in two kernels as well: descriptions into buffer 1
         // (level 1 fills it only afterwards), then the walk with every lane busy into the wave's log region
         const uint64_t desc_cap = ((ntiles + gd - 1) / gd) * 64;
@@ -1211,11 +1193,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         hipLaunchKernelGGL(walk_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, (const uint4 *)m->d_buf[1], desc_cap,
                            (const unsigned long long *)m->d_desc_cnt, (uint32_t)gdreg, m->dbg, m->d_buf[0], pl.log_cap,
                            pl.c_log, pl.d_hist, hist_nb, hist_shift, (uint64_t)0, 0, 0, (unsigned long long *)nullptr);
-    } else if (p.wk == 1) {
-        hipLaunchKernelGGL(scan_log_kernel, dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end, head_open,
-                           (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap, pl.c_log, pl.d_hist,
-                           hist_nb, hist_shift);
-    } else if (scan2) {
+    } else {
         // multi-limb keys, two kernels as well: descriptions (first k-mer + entering bases + validity) into buffer 1,
         // then the walk with every lane busy
         const int du = (2 * p.wk + 2 + 3) / 4;
@@ -1241,18 +1219,6 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             default: TSX_WIDE2(4); break;
         }
 #undef TSX_WIDE2
-    } else {
-        switch (p.wk) {
-            case 2: hipLaunchKernelGGL((scan_log_wide_kernel<2>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
-                                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
-                                       pl.c_log, pl.d_hist, hist_nb, hist_shift); break;
-            case 3: hipLaunchKernelGGL((scan_log_wide_kernel<3>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
-                                       head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
-                                       pl.c_log, pl.d_hist, hist_nb, hist_shift); break;
-            default: hipLaunchKernelGGL((scan_log_wide_kernel<4>), dim3(gs), dim3(NT), lut_bytes, st, pp, d_text, n, own_end,
-                                        head_open, (const uint32_t *)m->d_tile, ntiles, m->dbg, m->d_buf[0], pl.log_cap,
-                                        pl.c_log, pl.d_hist, hist_nb, hist_shift); break;
-        }
     }
     HIP_TRY(hipGetLastError());
     if (ev) { HIP_TRY(hipEventRecord(ev[2], st)); HIP_TRY(hipEventRecord(ev[3], st)); }
