@@ -430,7 +430,9 @@ def main():
         path_ms = (scan_ms + count_ms + build_ms) / pieces
         traffic = None
         prof = {}
-        pmc = os.path.join(ROOT, "profiles", "round2_pmc.json" if args.k == 31 else "round2_pmc_k%d.json" % args.k)
+        pmc = os.path.join(ROOT, "profiles", "round3_pmc.json" if args.k == 31 else "round3_pmc_k%d.json" % args.k)
+        if not os.path.exists(pmc) and args.k == 31:
+            pmc = os.path.join(ROOT, "profiles", "round2_pmc.json")
         if os.path.exists(pmc):
             try:
                 prof = json.load(open(pmc))

@@ -14,9 +14,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r%d" % ROUND)
-TRACES = ("partitioned", "atomic") if ROUND == 1 else ("k31", "k63")
+TRACES = ("partitioned", "atomic") if ROUND == 1 else (("k31", "k63") if ROUND == 2 else ("k31", "k63", "zipf63", "l33"))
 PMCDIR = "pmc_partitioned_*" if ROUND == 1 else "pmc_k31_*"
-BUILD = "tsx::build_segments_kernel" if ROUND == 1 else "tsx::build_segments_stream_kernel<false>"
+BUILD = ("tsx::build_segments_kernel" if ROUND == 1 else "tsx::build_segments_stream_kernel<false>" if ROUND == 2
+         else "tsx::build_segments_stream_kernel<false, true>")
 DST = os.path.join(ROOT, "profiles")
 TEXT_BYTES = 2081065118
 
@@ -67,7 +68,9 @@ for k, v in agg.items():
 # the scan kernel: fused with radix level 1 (scan_part_kernel) where the run used it
 # (or split in two: strip_desc_kernel + walk_part_kernel -- the scan stage is then both)
 TWO = "tsx::walk_part_kernel" in part["kernels"]
-SCAN = "tsx::walk_part_kernel" if TWO else ("tsx::scan_part_kernel" if "tsx::scan_part_kernel" in part["kernels"] else "tsx::scan_log_kernel")
+WALK = "tsx::walk_part_kernel" if "tsx::walk_part_kernel" in part["kernels"] else "tsx::walk_part_kernel<512>"
+TWO = TWO or WALK in part["kernels"]
+SCAN = WALK if TWO else ("tsx::scan_part_kernel" if "tsx::scan_part_kernel" in part["kernels"] else "tsx::scan_log_kernel")
 FUSED = SCAN != "tsx::scan_log_kernel"
 scan = part["kernels"].get(SCAN, {})
 part["kernel"] = SCAN
@@ -88,7 +91,7 @@ def plus(a, b):
 part["stages"] = {"scan": plus(nth_dispatch_bytes(SCAN, 0), nth_dispatch_bytes("tsx::strip_desc_kernel", 0)) if TWO
                           else nth_dispatch_bytes(SCAN, 0),
                   "level1": None if FUSED else nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0),
-                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>"), 0 if FUSED else 1),
+                  "level2": nth_dispatch_bytes("tsx::partition_ring_kernel" + ("" if ROUND == 1 else "<1>" if ROUND == 2 else "<1, 512, false>"), 0 if FUSED else 1),
                   "build": nth_dispatch_bytes(BUILD, 0)}
 part["hbm_bytes_whole_path_per_step"] = tot_r + tot_w
 lc = agg.get("tsx::line_count_kernel", {})
