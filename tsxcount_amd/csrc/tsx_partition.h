@@ -599,11 +599,18 @@ constexpr uint32_t SP_CAPBITS = 5;   // 32 words per ring: 15 may stay behind a 
 // wave; desc_prefix_kernel (one workgroup) turns the region sizes into offsets, desc_pack_kernel copies the regions
 // back to back.  total[0] = descriptions in all.
 __global__ __launch_bounds__(1024) void desc_prefix_kernel(const unsigned long long *cnt, uint32_t nregions,
-                                                           unsigned long long *offs, unsigned long long *total) {
+                                                           unsigned long long *offs, unsigned long long *total,
+                                                           uint64_t desc_cap, uint64_t out_cap, unsigned long long *stats) {
+    // (a region that ran past its capacity, or more descriptions than the caller's array holds: the sizes are bounded by
+    // construction -- one description per 16 / 64 start positions -- so either is a sizing bug; it is clamped here,
+    // consistently with desc_pack_kernel, and reported through the sticky failure counter instead of a short exchange)
     __shared__ unsigned long long s_w[16];
     const uint32_t tid = threadIdx.x, per = (nregions + 1023u) / 1024u;
-    unsigned long long sum = 0;
-    for (uint32_t i = 0; i < per; ++i) { const uint32_t r = tid * per + i; if (r < nregions) sum += cnt[r]; }
+    unsigned long long sum = 0, lost = 0;
+    for (uint32_t i = 0; i < per; ++i) {
+        const uint32_t r = tid * per + i;
+        if (r < nregions) { sum += min((unsigned long long)cnt[r], (unsigned long long)desc_cap); lost += cnt[r] > desc_cap ? cnt[r] - desc_cap : 0ULL; }
+    }
     const unsigned long long inc = wave_incl_scan64(sum);
     if ((tid & 63) == 63) s_w[tid >> 6] = inc;
     __syncthreads();
@@ -611,9 +618,13 @@ __global__ __launch_bounds__(1024) void desc_prefix_kernel(const unsigned long l
     for (uint32_t w = 0; w < (tid >> 6); ++w) base += s_w[w];
     for (uint32_t i = 0; i < per; ++i) {
         const uint32_t r = tid * per + i;
-        if (r < nregions) { offs[r] = base; base += cnt[r]; }
+        if (r < nregions) { offs[r] = base; base += min((unsigned long long)cnt[r], (unsigned long long)desc_cap); }
     }
-    if (tid == 1023) total[0] = base;
+    if (lost && stats) atomicAdd(&stats[ST_FAIL], lost);
+    if (tid == 1023) {
+        if (base > out_cap) { if (stats) atomicAdd(&stats[ST_FAIL], base - out_cap); base = out_cap; }
+        total[0] = base;
+    }
 }
 __global__ __launch_bounds__(256) void desc_pack_kernel(const uint4 *desc, uint64_t desc_cap, const unsigned long long *cnt,
                                                         const unsigned long long *offs, uint32_t nregions, uint4 *out,

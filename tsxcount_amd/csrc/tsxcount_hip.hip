@@ -1074,7 +1074,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         hipLaunchKernelGGL(strip_desc_kernel, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum, dsc.long_desc);
         hipLaunchKernelGGL(desc_prefix_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long *)d_cnt, (uint32_t)gdr,
-                           d_offs, d_tot);
+                           d_offs, d_tot, dcap, (uint64_t)dsc.cap, m->p.stats);
         hipLaunchKernelGGL(desc_pack_kernel, dim3(std::min(gdr, m->cus * 8)), dim3(256), 0, st, (const uint4 *)m->d_buf[1], dcap,
                            (const unsigned long long *)d_cnt, (const unsigned long long *)d_offs, (uint32_t)gdr, dsc.out,
                            dsc.cap * du, du);
