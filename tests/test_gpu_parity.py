@@ -1128,3 +1128,25 @@ def test_zipf_device_generator_and_analytic_counts(T, k, path):
     hot = synth.zipf_template(seed, t, p, k)
     assert c > n_reads // 8 and int(m.getKmerCounts(T.encode_many([hot], k))[0]) == c == ref[hot]
     m.close()
+
+
+@pytest.mark.parametrize("k,l", [(33, 23), (47, 24), (63, 23), (64, 23), (96, 23), (127, 22)])
+def test_wide_keys_two_radix_levels(T, k, l):
+    """k > 32 on a table split by two radix levels (strip_desc_wide_kernel + walk_log_wide_kernel, level 1 by exact offsets,
+    level 2 into sub-lists, build_segments_wide_stream_kernel): against the oracle, and a second count into the same table.
+    (A walk fused with level 1 for multi-limb keys was built and measured in round 3 -- rings of 2-word records are half as
+    deep, a third of the records took the direct route, 8.1 ms against 4.5 + 5.9 -- and dropped: DESIGN.md section 4.)"""
+    from oracle.oracle import Oracle
+    from tsxcount_amd import synth
+    text = synth.fastq(55 + k, 0, 1500)
+    o = Oracle(k, 22, 4, seed=1)
+    n = o.count_fastq(text)
+    kmers, counts = o.dump()
+    m = T.TSXHashMapHIP(l, 0, k)
+    m.set_path("partitioned")
+    for rep in (1, 2):
+        m.countFastq(text)
+        st = m.stats()
+        assert st["kmers_added"] == rep * n and st["distinct"] == len(kmers) and st["insert_failures"] == 0
+        assert np.array_equal(m.getKmerCounts(kmers), rep * counts)
+    m.close()
