@@ -89,3 +89,50 @@ def test_ranks_merge_equals_single_table(world):
         assert not (set(results[r]) & set(merged))  # owners are disjoint
         merged.update(results[r])
     assert merged == expect
+
+
+def _geometry_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tsxcount_amd.distributed import TorchComm, agreed_max, window_geometry, window_of
+    comm = TorchComm()
+    mine = [0, 40 << 20, 150 << 20][rank]          # rank 0 has NO reads; the ranks' texts straddle the 32 MiB window steps
+    big = agreed_max(mine, comm, torch.device("cpu"))
+    windows, win_bytes = window_geometry(big)
+    wins = [window_of(i, mine, win_bytes) for i in range(windows)]
+    # every window of every rank is a round of collectives: count them with a real one
+    for off, ln in wins:
+        t = torch.tensor([ln], dtype=torch.int64)
+        dist.all_reduce(t)
+    q.put((rank, big, windows, win_bytes, wins))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_uneven_and_empty_shards_agree_on_the_windows():
+    """ShardedCounter's window geometry: derived from the LARGEST text of any rank, so that a rank with a
+    short or empty shard runs the same number of rounds of collectives (empty windows at the 16-byte-aligned end of its
+    text) -- three gloo ranks with 0, 40 MiB and 150 MiB of text."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_geometry_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({(r[1], r[2], r[3]) for r in res}) == 1, "every rank must hold the same geometry"
+    big, windows, win_bytes = res[0][1:4]
+    assert big == 150 << 20 and windows == 4 and win_bytes % 4096 == 0 and windows * win_bytes >= big
+    for rank, _, _, _, wins in res:
+        mine = [0, 40 << 20, 150 << 20][rank]
+        assert len(wins) == windows and sum(ln for _, ln in wins) == mine
+        assert all(off % 16 == 0 and off + ln <= mine for off, ln in wins)
+        assert [ln for _, ln in wins] == sorted((ln for _, ln in wins), reverse=True)   # full windows first, then empty ones

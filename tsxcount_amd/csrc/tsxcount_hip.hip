@@ -980,8 +980,11 @@ static int run_partition_build(tsx_hip_map *m, const PartPlan &pl, const uint64_
                                        lists, lists_start, lists_cnt, lists_cap, pieces, pl.nseg, 0, fresh, build_la);
             }
         } else {   // multi-limb keys and / or slots: wave streams too (64 records of LDS per wave behind the segment)
-            const size_t ring_bytes = (size_t)16 * 64 * 8 * rw;
-            DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_stream_kernel<WKV>), dim3(gb), dim3(1024),
+            // a segment of <= 64 KiB (TSX_HIP_SEG_BITS): 512 threads, two workgroups per CU -- one sweeps while the other inserts
+            int wnt = (seg_bytes <= ((size_t)64 << 10)) ? 512 : 1024;
+            if (const char *e = getenv("TSX_HIP_BUILD_WNT")) wnt = std::min(1024, std::max(64 * (int)pieces, atoi(e) & ~63));
+            const size_t ring_bytes = (size_t)(wnt / 64) * 64 * 8 * rw;
+            DISPATCH_WK(m, hipLaunchKernelGGL((build_segments_wide_stream_kernel<WKV>), dim3(gb), dim3(wnt),
                                               seg_bytes + ring_bytes, st, pp, lists, lists_start, lists_cnt, lists_cap, pieces,
                                               pl.nseg, fresh));
         }

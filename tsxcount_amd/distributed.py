@@ -85,6 +85,33 @@ def agree(ok, comm, device):
     return bool(int(t.item()))
 
 
+def agreed_max(value, comm, device):
+    """The largest `value` of any rank (one tiny MAX all-reduce): what every rank must derive its window geometry from."""
+    if comm.world == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if comm.gloo else device)
+    comm.all_reduce(t, "max")
+    return int(t.item())
+
+
+def window_geometry(max_text_bytes, windows=None, min_window=32 << 20):
+    """(windows, win_bytes) of a step over texts of at most max_text_bytes: at most 4 windows of at least min_window
+    bytes (TSX_HIP_SHARD_WINDOWS overrides the count), window length a multiple of 4 KiB."""
+    if windows is None:
+        windows = int(os.environ.get("TSX_HIP_SHARD_WINDOWS", "0")) or max(1, min(4, max_text_bytes // min_window))
+    windows = max(1, int(windows))
+    return windows, max(4096, ((max_text_bytes + windows - 1) // windows + 4095) & ~4095)
+
+
+def window_of(i, nbytes, win_bytes):
+    """(offset, length) of window i of a text of nbytes: windows past the end of a short (or empty) text are empty, their
+    offset the end of the text rounded down to the 16 bytes the entry points ask for."""
+    off = i * win_bytes
+    if off >= nbytes:
+        return nbytes & ~15, 0
+    return off, min(win_bytes, nbytes - off)
+
+
 A2A_CHUNK = 128 << 20  # elements (1 GiB of int64) per pair and collective
 
 
@@ -233,15 +260,8 @@ class ShardedCounter:
         self.dev = torch.device("cuda", hmap.device)
         # Every rank must run the SAME number of windows (each window is a round of collectives) over the same
         # window length, whatever its own text size: both are derived from the largest text of any rank.
-        if self.world > 1:
-            t = torch.tensor([int(max_text_bytes)], dtype=torch.int64, device="cpu" if self.comm.gloo else self.dev)
-            self.comm.all_reduce(t, "max")
-            max_text_bytes = int(t.item())
-        self.max_text_bytes = int(max_text_bytes)
-        if windows is None:
-            windows = int(os.environ.get("TSX_HIP_SHARD_WINDOWS", "0")) or max(1, min(4, max_text_bytes // self.MIN_WINDOW))
-        self.windows = max(1, int(windows))
-        self.win_bytes = max(4096, ((max_text_bytes + self.windows - 1) // self.windows + 4095) & ~4095)
+        self.max_text_bytes = agreed_max(max_text_bytes, self.comm, self.dev)
+        self.windows, self.win_bytes = window_geometry(self.max_text_bytes, windows, self.MIN_WINDOW)
         i64 = dict(dtype=torch.int64, device=self.dev)
         self.send_cap = 0                         # key-exchange buffers: allocated by the first keys-mode step
         self.sums = torch.zeros((2,), **i64)      # [0] += keys written by the scans, [1] += keys read by the build
@@ -254,10 +274,7 @@ class ShardedCounter:
     def _window(self, i, nbytes):
         """(offset, length) of window i of a text of nbytes: windows past the end of a short (or empty) text are
         empty, their offset the end of the text rounded down to the 16 bytes the entry points ask for."""
-        off = i * self.win_bytes
-        if off >= nbytes:
-            return nbytes & ~15, 0
-        return off, min(self.win_bytes, nbytes - off)
+        return window_of(i, nbytes, self.win_bytes)
 
     def _ensure_key_buffers(self):
         """Send / receive / hot-list buffers of the key exchange, sized by the map's CURRENT record format (a FASTA
