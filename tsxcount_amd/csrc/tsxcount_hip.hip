@@ -411,9 +411,12 @@ static int derive_layout(tsx_hip_map *m, int k, int l, int s, int overflow_l, in
     p.k0mask = (p.K0 >= 64) ? ~0ULL : ((1ULL << p.K0) - 1ULL);
     p.lock_bit = lock ? (1ULL << p.K0) : 0ULL;
     p.slot_mask = (1ULL << l) - 1ULL;
-    // a segment fits a CU's LDS: 128 KiB = 2^14 one-limb slots, 2^13 two-limb, 2^12 three- or four-limb slots
+    // a segment fits a CU's LDS: 128 KiB = 2^14 one-limb slots or 2^12 four-limb slots (96 KiB of three-limb slots).  Two-limb
+    // slots: 2^12 = 64 KiB, so that TWO build workgroups of 512 threads share a CU and one sweeps while the other inserts
+    // (k = 63: build 13.3 -> 11.8 ms; 2^13-slot segments when that would need more than 2^18 of them).  One-limb slots at
+    // 64 KiB: build 4.41 -> 3.91 ms, but a radix level of 512 lists costs 0.5 ms more: 11.97 against 12.05 ms per step, not taken.
     const int smax = (W == 1) ? 14 : (W == 2) ? 13 : 12;
-    p.S = std::min(l, smax);
+    p.S = std::min(l, (W == 2 && l - 12 <= 18) ? 12 : smax);
     if (const char *e = getenv("TSX_HIP_SEG_BITS")) p.S = std::min(l, std::min(smax, std::max(8, atoi(e))));
     p.seg_mask = (1ULL << p.S) - 1ULL;
     const uint64_t maxr = (1ULL << p.R) - 1ULL;
