@@ -313,6 +313,24 @@ int tsx_hip_shard_filter_device(tsx_hip_map *m, const void *dev_desc, size_t n_d
 int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *dev_counts, size_t n,
                               void *stream);
 
+/* Minimizer exchange (any world size <= 16, 20 <= k <= 32; csrc/tsx_minimizer.h).  The owner of a k-mer is a function of
+ * its minimizer (the m-mer with the smallest hash value, m = min(11, k - 15)), so runs of consecutive k-mers share an owner
+ * and every GPU holds a WHOLE table (shard_bits = 0) of the k-mers it owns: no slot-range split, no merge, and nobody walks
+ * a position it does not own.  tsx_hip_mini_window_device describes a text window and splits the strip descriptions by
+ * owner: list o (packed, dev_counts[o] descriptions, a multiple of 64 -- holes carry no valid start) at
+ * dev_desc + o * cap_per_owner * 16 bytes, cap_per_owner >= tsx_hip_mini_capacity(win_len); dev_counts[nranks + b] =
+ * occurrences of the homopolymer k-mer of base b (A, C, G, T) in the window, which are NOT in the descriptions: the caller
+ * adds the totals on the owner of each (tsx_hip_mini_owner_host, tsx_hip_add_kmers_device); dev_kmer_sum += all k-mer
+ * occurrences of the window.  The receiver walks what it was sent with tsx_hip_shard_walk_device (long_desc = 2) and
+ * builds with tsx_hip_shard_build_l1_device.  tsx_hip_mini_owner_host: the owner of each one-limb k-mer (lookups). */
+int tsx_hip_mini_supported(tsx_hip_map *m);
+int tsx_hip_mini_capacity(tsx_hip_map *m, size_t text_bytes, int nranks, size_t *descs_per_owner_out);
+int tsx_hip_mini_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off, size_t win_len,
+                               int nranks, void *dev_desc, size_t cap_per_owner, void *dev_counts, void *dev_kmer_sum,
+                               void *stream);
+int tsx_hip_mini_owner_host(int k, int nranks, const uint64_t *kmers, size_t n, uint32_t *owners_out);
+
+
 /*
  * The multi-GPU run as ONE call from C++ (src/mains/main.cpp:404-507: one command runs the job): a group is one table per
  * GPU of this node, driven by one host thread per GPU inside the library (csrc/tsx_multi.cpp).

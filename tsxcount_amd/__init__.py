@@ -90,6 +90,10 @@ def lib():
     L.tsx_hip_shard_desc_window_device.argtypes = [vp, vp, sz, sz, sz, ctypes.c_int, vp, sz, vp, vp, vp]
     L.tsx_hip_shard_walk_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, sz, vp, vp]
     L.tsx_hip_shard_filter_device.argtypes = [vp, vp, sz, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, sz, vp, vp]
+    L.tsx_hip_mini_supported.argtypes = [vp]
+    L.tsx_hip_mini_capacity.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(sz)]
+    L.tsx_hip_mini_window_device.argtypes = [vp, vp, sz, sz, sz, ctypes.c_int, vp, sz, vp, vp, vp]
+    L.tsx_hip_mini_owner_host.argtypes = [ci, ci, u64p, sz, ctypes.POINTER(ctypes.c_uint32)]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None
     L.tsx_hip_get_layout.argtypes = [vp, ctypes.POINTER(Layout)]

@@ -433,7 +433,9 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
         if (!long_desc) {
             const unsigned long long hb = __ballot(vm != 0u);
             if (hb) {
-                if (vm) my[fill + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm);
+                // (bit 16: the description before this one is the strip before this one in the text -- desc_owner_split_kernel)
+                const uint32_t nbr = (lane > 0 && ((hb >> (lane - 1)) & 1ULL)) ? 0x10000u : 0u;
+                if (vm) my[fill + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm | nbr);
                 fill += (uint32_t)__builtin_popcountll(hb);
             }
         } else {   // lanes 4q .. 4q+3 hold 64 consecutive start positions: lane 4q writes for all four
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(NT, 4) void walk_log_kernel(TableParams p, const ui
                     else dn = rd[base + per + me];
                 }
             }
-            uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+            uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w & 0xFFFFu;   // (bit 16: strip_desc_kernel's neighbour mark)
             if (long_desc) {   // strip t of the four: bases 16 t .. 16 t + 47, validity bits 16 t .. 16 t + 15
                 const uint32_t t = (uint32_t)lane & 3u;
                 const uint32_t w0 = d.x, w1 = d.y, w2 = d.z, w3 = d.w, w4 = d2.x, w5 = d2.y;

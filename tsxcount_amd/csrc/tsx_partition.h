@@ -674,10 +674,11 @@ __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const u
     // Sharded runs (descriptions gathered from every GPU, tsx_hip_shard_walk_device): the descriptions are ONE packed
     // array of n_packed entries cut into runs of desc_cap; only the keys this GPU owns are kept (own_only); the launch
     // fills lists (b, dst_g0 + g) of dst_gtot per bucket.  Local runs: n_packed = 0, dst_g0 = 0, dst_gtot = G.
+    // own_only 2 (minimizer exchange, a table of this GPU's own): every key stays and is counted in emit_sum; no homopolymers.
     const uint32_t gl = dst_g0 + wg;
     auto word_of = [&](uint32_t b, uint32_t at) -> uint64_t * { return dst + ((uint64_t)(b * dst_gtot + gl) * (uint64_t)cap32 + at); };
     auto is_mine = [&](uint64_t hk) -> bool {
-        if (!own_only) return true;
+        if (own_only != 1) return true;
         const uint64_t h1[1] = {hk};
         return owner_shard<1>(p, h1) == p.shard;
     };
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const u
                     else dn = rd[base + per + me];
                 }
             }
-            uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w;
+            uint32_t cw0 = d.x, cw1 = d.y, cw2 = d.z, vm = d.w & 0xFFFFu;   // (bit 16: strip_desc_kernel's neighbour mark)
             if (long_desc) {   // strip t of the four: bases 16 t .. 16 t + 47, validity bits 16 t .. 16 t + 15
                 const uint32_t t = tid & 3u;
                 const uint32_t w0 = d.x, w1 = d.y, w2 = d.z, w3 = d.w, w4 = d2.x, w5 = d2.y;
@@ -834,8 +835,8 @@ __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const u
                     const uint32_t w1 = (ws == 0u) ? cw1 : (ws == 1u) ? cw2 : 0u;
                     inc = __funnelshift_r(w0, w1, sh);
                 }
-            uint32_t homm;   // bit j: the k-mer at strip position j is a homopolymer
-            {
+            uint32_t homm = 0;   // bit j: the k-mer at strip position j is a homopolymer
+            if (own_only != 2) {   // (own_only 2, minimizer exchange: the sender took them out and counted them)
                 const uint64_t dlo = lo ^ ((lo >> 2) | (hi << 62)), dhi = hi ^ (hi >> 2);
                 uint64_t rlo = (dlo | (dlo >> 1)) & 0x5555555555555555ULL, rhi = (dhi | (dhi >> 1)) & 0x5555555555555555ULL;
                 uint32_t span = 1;
@@ -902,9 +903,11 @@ __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const u
                     }
                     uint32_t m4 = s4;   // positions of this quarter whose keys this GPU keeps
                     if (own_only) {
+                        if (own_only == 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (((s4 >> j) & 1u) && !is_mine(hs[j])) m4 &= ~(1u << j);
+                            for (int j = 0; j < 4; ++j)
+                                if (((s4 >> j) & 1u) && !is_mine(hs[j])) m4 &= ~(1u << j);
+                        }
                         emitted += (unsigned long long)__popc(m4);
                     }
                     if (__ballot(m4 != 0u) != 0ULL) {

@@ -4,6 +4,7 @@
 #include "../../include/tsxcount_hip.h"
 #include "tsx_kernels.h"
 #include "tsx_partition.h"
+#include "tsx_minimizer.h"
 #include "tsx_inflate.h"
 
 #include <mutex>
@@ -1029,7 +1030,9 @@ struct ShardOut {
 // split by owner into shard_send (counts per owner to shard_counts), hot keys to `hot`.
 // Sharded run, description exchange: the piece is only DESCRIBED (strip_desc_kernel), the descriptions packed
 // into out[0 .. *count).
-struct DescOut { uint4 *out = nullptr; uint64_t cap = 0; unsigned long long *count = nullptr, *sum = nullptr; int long_desc = 0; };
+// owners > 0 (minimizer exchange): one packed list per owner GPU at out + o * cap, count[0 .. owners) their lengths,
+// count[owners .. owners + 4) the homopolymer k-mer occurrences taken out of the descriptions, per base.
+struct DescOut { uint4 *out = nullptr; uint64_t cap = 0; unsigned long long *count = nullptr, *sum = nullptr; int long_desc = 0; int owners = 0; };
 
 static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
                            hipStream_t st, ShardOut sh = ShardOut(), HotOut hot = HotOut(), DescOut dsc = DescOut()) {
@@ -1072,13 +1075,30 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         if (rcd != TSX_HIP_OK) return rcd;
         {   // region sizes | region offsets | total
             size_t have = m->desc_cnt_entries;
-            rcd = grow(st, m->d_desc_cnt, have, ((size_t)2 * gdr + 8) * 8);
+            rcd = grow(st, m->d_desc_cnt, have, ((size_t)2 * gdr + 16) * 8 + (size_t)MZ_MAX_RANKS * m->cus * MZ_WG_PER_CU * 4);
             m->desc_cnt_entries = have;
             if (rcd != TSX_HIP_OK) return rcd;
         }
         unsigned long long *d_cnt = m->d_desc_cnt, *d_offs = d_cnt + gdr, *d_tot = d_offs + gdr;
         hipLaunchKernelGGL(strip_desc_kernel, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum, dsc.long_desc);
+        if (dsc.owners) {   // owner = f(minimizer): split the wave regions into one packed list per owner
+            static const int mz_wgs = getenv("TSX_HIP_MZ_WGS") ? std::min(MZ_WG_PER_CU, std::max(1, atoi(getenv("TSX_HIP_MZ_WGS")))) : MZ_WG_PER_CU;
+            static const int mz_merge = getenv("TSX_HIP_MZ_MERGE") ? atoi(getenv("TSX_HIP_MZ_MERGE")) : 1;
+            const int gsp = std::min(gdr, m->cus * mz_wgs);
+            uint32_t *d_used = (uint32_t *)(d_tot + 8);   // chunks taken per (owner, workgroup)
+            hipLaunchKernelGGL(desc_owner_split_kernel, dim3(gsp), dim3(MZ_NT), 0, st, m->p, (const uint4 *)m->d_buf[1], dcap,
+                               (const unsigned long long *)d_cnt, (uint32_t)gdr, (uint32_t)dsc.owners, dsc.out,
+                               (uint64_t)dsc.cap, d_used, dsc.count + dsc.owners, mz_merge);
+            hipLaunchKernelGGL(desc_owner_finish_kernel, dim3(64, dsc.owners), dim3(MZ_NT), 0, st, (const uint32_t *)d_used,
+                               (uint32_t)gsp, (uint32_t)dsc.owners, dsc.out, (uint64_t)dsc.cap, dsc.count, m->p.stats);
+            HIP_TRY(hipGetLastError());
+            if (ev) {
+                for (int i = 2; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
+                m->ev_open.push_back((long)(ev - m->ev.data()));
+            }
+            return TSX_HIP_OK;
+        }
         hipLaunchKernelGGL(desc_prefix_kernel, dim3(1), dim3(1024), 0, st, (const unsigned long long *)d_cnt, (uint32_t)gdr,
                            d_offs, d_tot, dcap, (uint64_t)dsc.cap, m->p.stats);
         hipLaunchKernelGGL(desc_pack_kernel, dim3(std::min(gdr, m->cus * 8)), dim3(256), 0, st, (const uint4 *)m->d_buf[1], dcap,
@@ -1489,6 +1509,52 @@ extern "C" int tsx_hip_shard_desc_window_device(tsx_hip_map *m, const void *dev_
     return run_fastq_piece(m, (const uint8_t *)dev_text + win_off, len, win_len, win_off ? -1 : 0, st, ShardOut(), HotOut(), dsc);
 }
 
+// ---- owner = f(minimizer) (tsx_minimizer.h): every GPU holds a whole table of the k-mers it owns -------------------
+// tsx_hip_mini_window_device describes one text window and splits the descriptions by owner GPU; the caller ships list o
+// to GPU o (all-to-all), walks what it received with tsx_hip_shard_walk_device (a map with shard_bits = 0 keeps every key),
+// builds with tsx_hip_shard_build_l1_device and adds the homopolymer totals it owns (tsx_hip_add_kmers_device).
+extern "C" int tsx_hip_mini_supported(tsx_hip_map *m) {
+    return (m && tsx_hip_shard_l1_supported(m) && m->p.lg == m->p.l && mz_supported((uint32_t)m->p.k)) ? 1 : 0;
+}
+
+extern "C" int tsx_hip_mini_capacity(tsx_hip_map *m, size_t text_bytes, int nranks, size_t *descs_per_owner_out) {
+    if (!m || !descs_per_owner_out || nranks < 1 || nranks > MZ_MAX_RANKS) return TSX_HIP_EINVAL;
+    // a strip of 16 start positions yields at most one description per owner; every workgroup may leave one chunk open
+    *descs_per_owner_out = text_bytes / 16 + 4096 + (size_t)2 * MZ_CHUNK * (size_t)m->cus * MZ_WG_PER_CU;
+    return TSX_HIP_OK;
+}
+
+extern "C" int tsx_hip_mini_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off, size_t win_len,
+                                          int nranks, void *dev_desc, size_t cap_per_owner, void *dev_counts,
+                                          void *dev_kmer_sum, void *stream) {
+    if (!m || (!dev_text && n_total) || ((uintptr_t)dev_text & 15) || (win_off & 15) || !dev_desc || ((uintptr_t)dev_desc & 15) ||
+        !dev_counts || win_off > n_total || win_len > n_total - win_off || nranks < 1 || nranks > MZ_MAX_RANKS)
+        return TSX_HIP_EINVAL;
+    if (!tsx_hip_mini_supported(m)) return TSX_HIP_EINVAL;
+    if (win_len >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;
+    size_t need = 0;
+    tsx_hip_mini_capacity(m, win_len, nranks, &need);
+    if (cap_per_owner < need) return TSX_HIP_ERANGE;
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t st = pick_stream(m, stream);
+    if (win_off == 0) HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(dev_counts, 0, ((size_t)nranks + 4) * 8, st));
+    if (win_len == 0) return TSX_HIP_OK;
+    DescOut dsc;
+    dsc.out = (uint4 *)dev_desc; dsc.cap = cap_per_owner; dsc.count = (unsigned long long *)dev_counts;
+    dsc.sum = (unsigned long long *)dev_kmer_sum;
+    dsc.owners = nranks;
+    const size_t halo = (size_t)m->p.k - 1;
+    const size_t len = std::min(win_len + halo, n_total - win_off);
+    return run_fastq_piece(m, (const uint8_t *)dev_text + win_off, len, win_len, win_off ? -1 : 0, st, ShardOut(), HotOut(), dsc);
+}
+
+extern "C" int tsx_hip_mini_owner_host(int k, int nranks, const uint64_t *kmers, size_t n, uint32_t *owners_out) {
+    if (!mz_supported((uint32_t)k) || nranks < 1 || nranks > MZ_MAX_RANKS || (!kmers && n) || (!owners_out && n)) return TSX_HIP_EINVAL;
+    for (size_t i = 0; i < n; ++i) owners_out[i] = mz_owner_of_kmer(kmers[i], (uint32_t)k, (uint32_t)nranks);
+    return TSX_HIP_OK;
+}
+
 // Walks n_desc packed descriptions (any GPU's), keeps the keys this shard owns and partitions them by radix level 1
 // into list set `slot` of `nslots` (slot 0 plans for est_total_keys owned keys in all).  dev_emit_sum += k-mer
 // occurrences kept.  Then tsx_hip_shard_build_l1_device.
@@ -1535,6 +1601,14 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     // this GPU keeps one key in 2^shard_bits: a ring flush every 1, 2 or 4 quarter strips (walk_part_kernel)
     const uint32_t nown = 1u << (m->p.lg - m->p.l);
     uint32_t flush_q = nown >= 4 ? 4u : (nown == 2 ? 2u : 1u);
+    // long_desc & 2: what the minimizer exchange sent to a map with shard_bits = 0 -- every key stays, homopolymers were
+    // taken out by the sender, about half of a description's 16 positions are valid (a flush every second quarter)
+    const int own_mode = (long_desc & 2) ? 2 : 1;
+    if (own_mode == 2) {
+        if (nown != 1) return TSX_HIP_EINVAL;
+        flush_q = 2u;
+    }
+    long_desc &= 1;
     if (const char *e = getenv("TSX_HIP_WALK_FLUSHQ")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) flush_q = (uint32_t)v; }
     TableParams pp = m->p;
     pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
@@ -1543,13 +1617,13 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
         hipLaunchKernelGGL(walk_part_kernel<1024>, dim3(gw), dim3(1024), lds, st, pp, (const uint4 *)dev_desc, chunk,
                            (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                            (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
-                           m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
+                           m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, own_mode,
                            (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0, flush_q);
     else
         hipLaunchKernelGGL(walk_part_kernel<SP_NT>, dim3(gw), dim3(SP_NT), lds, st, pp, (const uint4 *)dev_desc, chunk,
                            (const unsigned long long *)nullptr, gw, m->dbg, pl.buf1, pl.cap1, pl.c_l1, pl.nb1,
                            (uint32_t)(m->p.l - pl.b1), m->d_ovq + ((size_t)nq2 + (size_t)slot * gw) * OVQ_CAP,
-                           m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, 1,
+                           m->d_ovq_cnt + nq2 + (size_t)slot * gw, OVQ_CAP, (uint64_t)n_desc, slot * gw, pl.G1, own_mode,
                            (unsigned long long *)dev_emit_sum, long_desc ? 1 : 0, flush_q);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
