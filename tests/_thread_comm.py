@@ -46,6 +46,14 @@ class ThreadComm:
         assert at == out.shape[0]
         self._done()
 
+    def all_to_all_lists(self, outs, inps):
+        self._publish(list(inps))
+        for p in range(self.world):
+            src = self.w.slots[p][self.rank]
+            assert src.numel() == outs[p].numel(), "sizes of sender %d and receiver %d disagree" % (p, self.rank)
+            outs[p].copy_(src)
+        self._done()
+
     def all_gather(self, out, inp):
         self._publish(inp)
         n = inp.shape[0]

@@ -136,3 +136,50 @@ def test_ranks_with_uneven_and_empty_shards_agree_on_the_windows():
         assert len(wins) == windows and sum(ln for _, ln in wins) == mine
         assert all(off % 16 == 0 and off + ln <= mine for off, ln in wins)
         assert [ln for _, ln in wins] == sorted((ln for _, ln in wins), reverse=True)   # full windows first, then empty ones
+
+
+def _mz_owner_py(x, k, nranks):
+    """The minimizer owner rule of csrc/tsx_minimizer.h, restated: m = min(11, k - 15); value of an m-mer = bit 31 if it
+    starts or ends with AAA, below it ((x * 0x9E3779 + 0x2B5A3D) mod 4^m) top-aligned in 31 bits; the minimizer is the m-mer
+    of the k-mer with the smallest value; owner = (bits 8..23 of (value >> (31 - 2m)) * 0xC2B2AF) * nranks >> 16."""
+    m = min(11, k - 15)
+    mb = 2 * m
+    mask = (1 << mb) - 1
+    best = 0xFFFFFFFF
+    for j in range(k - m + 1):
+        v = (x >> (2 * j)) & mask
+        pen = 0x80000000 if ((v & 63) == 0 or (v >> (mb - 6)) == 0) else 0
+        key = pen | ((((v * 0x9E3779 + 0x2B5A3D) & 0xFFFFFFFF) & mask) << (31 - mb))
+        best = min(best, key)
+    t = best >> (31 - mb)
+    u = (((t * 0xC2B2AF) & 0xFFFFFFFF) >> 8) & 0xFFFF
+    return (u * nranks) >> 16
+
+
+def test_minimizer_owner_function():
+    """tsx_hip_mini_owner_host against its restatement, and what the exchange relies on: owners in range, consecutive k-mers
+    of a random sequence mostly share one (runs of about 12), every rank gets its share."""
+    import numpy as np
+    import tsxcount_amd as T
+    from tsxcount_amd import distributed as TD
+    rng = np.random.default_rng(5)
+    for k in (20, 21, 25, 26, 27, 31, 32):
+        for world in (1, 2, 3, 8, 16):
+            xs = rng.integers(0, 1 << 62, size=300, dtype=np.uint64) & np.uint64((1 << (2 * k)) - 1)
+            xs[:4] = [int(T.encode(b * k, k)[0]) for b in "ACGT"]
+            got = TD.owner_of(xs, k, world)
+            assert got.max() < world
+            assert [int(g) for g in got] == [_mz_owner_py(int(x), k, world) for x in xs], (k, world)
+    k, world, n = 31, 8, 60000
+    codes = rng.integers(0, 4, size=n + k).astype(np.uint64)
+    km = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        km |= codes[j:j + n] << np.uint64(2 * j)
+    own = TD.owner_of(km, k, world)
+    runs = 1 + int((own[1:] != own[:-1]).sum())
+    assert 9 < n / runs < 16, n / runs
+    share = np.bincount(own, minlength=world) / n
+    assert share.min() > 0.08 and share.max() < 0.17, share
+    import pytest
+    with pytest.raises(T.TSXException):
+        TD.owner_of(km[:4], 19, 8)      # k < 20: the 16 windows of a strip would not share a core

@@ -942,6 +942,121 @@ def test_sharded_counting_on_one_gpu(world):
         assert "SHARD OK" in o
 
 
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_minimizer_counting_on_one_gpu(world):
+    """The minimizer exchange (owner of a k-mer = f(its minimizer), every rank a whole table of what it owns) with 2, 3 and
+    4 ranks on cuda:0 and gloo collectives: every k-mer of the oracle's dump on exactly the rank tsx_hip_mini_owner_host
+    names, with the oracle's count; k = 20 .. 32, FASTA, empty and uneven shards, repeated and cleared steps."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.path.join(ROOT, "tests", "_mini_worker.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "MINI OK" in o
+
+
+def test_minimizer_counting_world_8_in_one_process(T):
+    """Eight ranks of the minimizer exchange as eight THREADS on cuda:0 (collectives = device copies behind a barrier,
+    tests/_thread_comm.py): the world size of the 8-GPU node.  Sum over ranks == oracle, every k-mer on the rank its
+    minimizer names and only there."""
+    import threading
+    import torch
+    from _thread_comm import ThreadComm, ThreadWorld
+    from oracle.oracle import Oracle
+    from tsxcount_amd import distributed as TD
+    from tsxcount_amd import synth
+    world, k, l, n_reads = 8, 31, 23, 640
+    tw = ThreadWorld(world)
+    whole = Oracle(k, 21, 4, seed=1)
+    whole.count_fastq(synth.fastq(68, 0, n_reads))
+    kmers, counts = whole.dump()
+    owner = TD.owner_of(kmers, k, world)
+    got = [None] * world
+    errs = []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            first, cnt = TD.shard_reads(n_reads, rank, world)
+            text = synth.fastq(68, first, cnt)
+            buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")
+            m = T.TSXHashMapHIP(l, 0, k, device=0)
+            mc = TD.MinimizerCounter(m, len(text), group=ThreadComm(tw, rank), windows=3)
+            torch.cuda.synchronize()
+            mc.step(buf.data_ptr(), len(text))
+            assert mc.last["key_sum_diff"] == 0 and mc.last["mode"] == "minimizer"
+            st = m.stats()
+            assert st["insert_failures"] == 0
+            got[rank] = (m.getKmerCounts(kmers), st)
+            m.close()
+        except BaseException as e:   # noqa: BLE001 -- a dead rank must not leave the others in a barrier
+            errs.append((rank, repr(e)))
+            tw.barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errs, errs
+    for r in range(world):
+        assert np.array_equal(got[r][0], np.where(owner == r, counts, 0).astype(np.uint64)), "rank %d" % r
+    assert sum(g[1]["distinct"] for g in got) == len(kmers)
+    assert sum(g[1]["count_sum"] for g in got) == int(counts.sum())
+
+
+@pytest.mark.parametrize("k,world", [(20, 2), (23, 7), (26, 16), (31, 8), (32, 5)])
+def test_minimizer_split_lists_hold_what_the_host_function_says(T, k, world):
+    """desc_owner_split_kernel against tsx_hip_mini_owner_host: list o of a text's split, walked alone into an empty table,
+    must yield exactly the k-mers (with their counts) whose owner the host function says is o -- homopolymers excepted,
+    which are counted on the side."""
+    import ctypes
+    import torch
+    from oracle.oracle import Oracle
+    from tsxcount_amd import distributed as TD
+    from tsxcount_amd import synth
+    text = synth.fastq(69 + k, 0, 500)
+    ora = Oracle(k, 21, 4, seed=1)
+    ora.count_fastq(text)
+    kmers, counts = ora.dump()
+    owner = TD.owner_of(kmers, k, world)
+    hom = np.array([T.decode(km, k) in ("A" * k, "C" * k, "G" * k, "T" * k) for km in kmers])
+    buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")
+    m = T.TSXHashMapHIP(23, 0, k)
+    L, vp = m._lib, ctypes.c_void_p
+    assert L.tsx_hip_mini_supported(m.handle)
+    cap = ctypes.c_size_t(0)
+    assert L.tsx_hip_mini_capacity(m.handle, len(text) + 256, world, ctypes.byref(cap)) == 0
+    cap = cap.value
+    i64 = dict(dtype=torch.int64, device="cuda:0")
+    dsc = torch.empty((2 * cap * world,), **i64)
+    cnt = torch.zeros((world + 4,), **i64)
+    emit = torch.zeros((2,), **i64)
+    assert L.tsx_hip_mini_window_device(m.handle, vp(buf.data_ptr()), len(text), 0, len(text), world, vp(dsc.data_ptr()), cap,
+                                        vp(cnt.data_ptr()), vp(emit.data_ptr()), None) == 0
+    m.sync()
+    c = [int(x) for x in cnt.tolist()]
+    assert sum(c[world:]) == int(counts[hom].sum()) and all(x % 64 == 0 and x <= cap for x in c[:world])
+    walked = 0
+    for o in range(world):
+        m.clear()
+        emit.zero_()
+        assert L.tsx_hip_shard_walk_device(m.handle, vp(dsc.data_ptr() + o * cap * 16), c[o], 2, 0, 1, len(text), vp(emit[1:].data_ptr()), None) == 0
+        assert L.tsx_hip_shard_build_l1_device(m.handle, None) == 0
+        m.sync()
+        want = np.where((owner == o) & ~hom, counts, 0).astype(np.uint64)
+        assert np.array_equal(m.getKmerCounts(kmers), want), "list %d" % o
+        assert m.stats()["distinct"] == int(((owner == o) & ~hom).sum())
+        walked += int(emit[1].item())
+    assert walked + sum(c[world:]) == int(counts.sum())
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_config5_k127_load_0p8_overflow_merge(world):
     """BASELINE config 5 at oracle scale: k = 127 (4-limb keys), --s=2 counters so that counts carry into the

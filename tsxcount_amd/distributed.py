@@ -2,6 +2,9 @@
 
 Two ways to combine the ranks' work:
 
+MinimizerCounter one whole table per rank, owner of a k-mer = f(its minimizer): strip descriptions
+                 masked per owner travel (about 1.8 B per k-mer occurrence), every rank walks only what
+                 it owns.  Any world size <= 16, 20 <= k <= 32.  The better exchange from 4 ranks on.
 ShardedCounter   ONE table sharded by slot range.  Every rank scans its own reads in
                  windows; the hashed keys of a window travel to the rank that owns their
                  slot range through ONE all-to-all (RCCL over xGMI) and are built there.
@@ -51,6 +54,23 @@ class TorchComm:
         else:
             dist.all_to_all_single(out, inp, output_split_sizes=out_sizes, input_split_sizes=in_sizes,
                                    group=self.group)
+
+    def all_to_all_lists(self, outs, inps):
+        """outs[p] <- what rank p has in its inps[my rank]: the pieces need not be neighbours in memory (RCCL: grouped
+        send / recv straight from and into them, no packing on either side)."""
+        if self.gloo:
+            dev = next((t.device for t in outs if t.is_cuda), None)
+            torch.cuda.current_stream(dev).synchronize() if dev is not None else None
+            flat = torch.cat([t.reshape(-1).cpu() for t in inps])
+            o = torch.empty((sum(t.numel() for t in outs),), dtype=flat.dtype)
+            dist.all_to_all_single(o, flat, output_split_sizes=[t.numel() for t in outs],
+                                   input_split_sizes=[t.numel() for t in inps], group=self.group)
+            at = 0
+            for t in outs:
+                t.copy_(o[at:at + t.numel()].view(t.shape))
+                at += t.numel()
+        else:
+            dist.all_to_all(list(outs), list(inps), group=self.group)
 
     def all_gather(self, out, inp):
         if self.gloo:
@@ -557,3 +577,177 @@ class ShardedCounter:
                                "over all ranks = %d)" % diff)
         m.sync()
         return n_recv_total
+
+
+class MinimizerCounter:
+    """Multi-GPU counting with owner(k-mer) = f(minimizer of the k-mer) (csrc/tsx_minimizer.h; 20 <= k <= 32, world <= 16,
+    any world size).  Every rank holds a WHOLE table (TSXHashMapHIP without shard_bits) of the k-mers it owns; nothing is
+    merged at the end, and a lookup goes to rank owner_of(kmers).  step() counts one device text of this rank's reads, cut
+    into W windows:
+
+        compute stream   split(0) split(1) walk(0) split(2) walk(1) ...  walk(W-1)  level 2 + build + homopolymers
+        exchange stream        sizes(0) a2a(0)   sizes(1) a2a(1) ...
+
+    split(i)  tsx_hip_mini_window_device: window i -> strip descriptions, one packed list per owner rank (consecutive
+              k-mers mostly share a minimizer, so a strip of 16 starts ends up in about 1.8 lists); homopolymer k-mers
+              (poly-A tails: ONE key, one owner) are counted here instead and leave the descriptions
+    sizes(i)  one small all-to-all: per pair {descriptions to come, the sender's status}; the only host wait of the window,
+              while split(i+1) is already queued
+    a2a(i)    grouped send / recv straight from the lists into window i's receive buffer (back to back by source rank)
+    walk(i)   tsx_hip_shard_walk_device (flag 2): first window + rolls + radix level 1 over what arrived, every key kept
+    build     ONE tsx_hip_shard_build_l1_device; the homopolymer totals (summed over ranks and windows in the step's final
+              all-reduce) are added on their owners
+
+    Integrity: sum over ranks of (k-mer occurrences described - walked - homopolymers) must be 0."""
+
+    MIN_WINDOW = 32 << 20
+
+    def __init__(self, hmap, max_text_bytes, group=None, windows=None):
+        from . import _check
+        self.m = hmap
+        self.comm = _comm(group)
+        self.world, self.rank = self.comm.world, self.comm.rank
+        L = hmap._lib
+        if hmap.layout.shard_bits != 0 or not L.tsx_hip_mini_supported(hmap.handle):
+            raise ValueError("minimizer exchange: 20 <= k <= 32, one-limb slots, a table split by two radix levels, shard_bits = 0")
+        if not 1 <= self.world <= 16:
+            raise ValueError("minimizer exchange: at most 16 ranks")
+        self.dev = torch.device("cuda", hmap.device)
+        self.max_text_bytes = agreed_max(max_text_bytes, self.comm, self.dev)
+        self.windows, self.win_bytes = window_geometry(self.max_text_bytes, windows, self.MIN_WINDOW)
+        cap = ctypes.c_size_t(0)
+        _check(L.tsx_hip_mini_capacity(hmap.handle, self.win_bytes + 256, self.world, ctypes.byref(cap)))
+        self.cap = cap.value
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        self.dsc = [torch.empty((2 * self.cap * self.world,), **i64) for _ in range(2)]     # [owner][cap] descriptions of 16 bytes
+        self.cnt = [torch.zeros((self.world + 4,), **i64) for _ in range(2)]                # list lengths, then homopolymers per base
+        self.recv = [torch.zeros((0,), **i64) for _ in range(self.windows)]
+        self.emit = torch.zeros((2,), **i64)      # [0] += occurrences described, [1] += occurrences walked
+        self.hom = torch.zeros((4,), **i64)
+        self.cs = torch.cuda.Stream(self.dev)
+        self.xs = torch.cuda.Stream(self.dev)
+        self.ev_scan = [torch.cuda.Event() for _ in range(2)]
+        self.ev_exch = [torch.cuda.Event() for _ in range(2)]
+        from . import encode
+        import numpy as np
+        self.hom_kmers = np.stack([encode("ACGT"[b] * hmap.k, hmap.k) for b in range(4)])
+        self.hom_owner = owner_of(self.hom_kmers, hmap.k, self.world)
+        self.hom_dev = torch.from_numpy(self.hom_kmers.astype(np.int64)).to(self.dev)
+        self.last = {}
+
+    def step(self, text_ptr, nbytes):
+        from . import OK, TSXException, _check
+        m, L, vp = self.m, self.m._lib, ctypes.c_void_p
+        world, rank, comm = self.world, self.rank, self.comm
+        if nbytes > self.max_text_bytes:
+            raise ValueError("minimizer step: text of %d bytes, the counter was made for %d" % (nbytes, self.max_text_bytes))
+        nwin = self.windows
+        i64 = dict(dtype=torch.int64, device=self.dev)
+        self.cs.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.cs):
+            self.emit.zero_()
+            self.hom.zero_()
+        late = None      # a failure only this rank has seen: it stays in the collectives, all raise after the last all-reduce
+
+        def split(i):
+            b = i & 1
+            off, ln = window_of(i, nbytes, self.win_bytes)
+            rc = L.tsx_hip_mini_window_device(m.handle, vp(text_ptr), nbytes, off, ln, world, vp(self.dsc[b].data_ptr()),
+                                              self.cap, vp(self.cnt[b].data_ptr()), vp(self.emit.data_ptr()),
+                                              vp(self.cs.cuda_stream))
+            with torch.cuda.stream(self.cs):
+                self.hom += self.cnt[b][world:]
+            self.ev_scan[b].record(self.cs)
+            return rc
+
+        rc_next = split(0)
+        est_total, n_recv_total, n_sent = 0, 0, 0
+        for i in range(nwin):
+            b = i & 1
+            rc_this = rc_next
+            if i + 1 < nwin:
+                if i >= 1:
+                    self.cs.wait_event(self.ev_exch[(i + 1) & 1])   # exchange i-1 has read the lists split(i+1) overwrites
+                rc_next = split(i + 1)                              # queued before the host waits for window i
+            with torch.cuda.stream(self.xs):
+                self.xs.wait_event(self.ev_scan[b])
+                meta_in = torch.empty((world, 2), **i64)
+                meta_in[:, 0] = self.cnt[b][:world]
+                meta_in[:, 1] = int(rc_this)
+                meta_out = torch.empty_like(meta_in)
+                comm.all_to_all(meta_out, meta_in)
+                host = torch.cat([meta_out.view(-1), self.cnt[b][:world]]).cpu()   # the one host wait of the window
+                mo = host[:2 * world].view(world, 2)
+                mine = [min(int(x), self.cap) for x in host[2 * world:].tolist()]
+                status = [int(x) for x in mo[:, 1].tolist()]
+                if any(s != OK for s in status):     # every rank sees the same statuses (a rank's own travels to all): all leave together
+                    late = late or (i, status)
+                    break
+                rs = [min(int(x), self.cap) for x in mo[:, 0].tolist()]
+                n_recv = sum(rs)
+                if self.recv[i].numel() < 2 * n_recv:
+                    self.recv[i] = torch.empty((2 * n_recv + 4096,), **i64)
+                outs, at = [], 0
+                for p in range(world):
+                    outs.append(self.recv[i][2 * at:2 * (at + rs[p])])
+                    at += rs[p]
+                inps = [self.dsc[b][2 * p * self.cap:2 * (p * self.cap + mine[p])] for p in range(world)]
+                if world > 1:
+                    comm.all_to_all_lists(outs, inps)
+                else:
+                    outs[0].copy_(inps[0])
+                self.ev_exch[b].record(self.xs)
+            n_recv_total += n_recv
+            n_sent += sum(mine) - mine[rank]
+            self.cs.wait_event(self.ev_exch[b])
+            if i == 0:
+                # k-mer occurrences this rank will own: its share of everybody's text (a description stands for about 9)
+                est_total = int(max(n_recv, 4096) * 16 * nwin * 1.1) + 65536
+            if late is None:
+                rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.recv[i].data_ptr()), n_recv, 2, i, nwin, est_total,
+                                                 vp(self.emit[1:].data_ptr()), vp(self.cs.cuda_stream))
+                if rc != OK:
+                    late = (i, [rc])
+        self.cs.wait_stream(self.xs)
+        failure = late
+        if failure is None and n_recv_total:
+            rc = L.tsx_hip_shard_build_l1_device(m.handle, vp(self.cs.cuda_stream))
+            if rc != OK:
+                failure = (nwin, [rc])
+        self.cs.synchronize()
+        self.xs.synchronize()
+        em = [int(x) for x in self.emit.tolist()]
+        hom = [int(x) for x in self.hom.tolist()]
+        fin = torch.tensor([em[0] - em[1] - sum(hom), 0 if failure is None else 1] + hom, dtype=torch.int64,
+                           device="cpu" if comm.gloo else self.dev)
+        comm.all_reduce(fin, "sum") if world > 1 else None
+        red = [int(x) for x in fin.tolist()]
+        diff, nfail, hom_all = red[0], red[1], red[2:6]
+        self.last = {"windows": nwin, "received_descriptions": n_recv_total, "sent_bytes": 16 * n_sent, "key_sum_diff": diff,
+                     "mode": "minimizer", "homopolymers": hom_all}
+        if nfail:
+            if failure is not None:
+                bad = [s for s in failure[1] if s != OK]
+                _check(bad[0])
+            raise TSXException(-4, "minimizer step: another rank failed")
+        if diff != 0:
+            raise RuntimeError("minimizer step: k-mer occurrences described - walked - homopolymers, over all ranks = %d" % diff)
+        # the homopolymer k-mers, on their owners, with the totals of all ranks
+        sel = [b for b in range(4) if hom_all[b] and int(self.hom_owner[b]) == rank]
+        if sel:
+            keys = self.hom_dev[sel].contiguous()
+            cnts = torch.tensor([hom_all[b] for b in sel], **i64)
+            _check(L.tsx_hip_add_kmers_device(m.handle, vp(keys.data_ptr()), vp(cnts.data_ptr()), len(sel), None))
+        m.sync()
+        return em[1]
+
+
+def owner_of(kmers, k, world):
+    """Rank that owns each one-limb k-mer under the minimizer exchange (numpy uint32)."""
+    import numpy as np
+    from . import _check, lib
+    a = np.ascontiguousarray(kmers, dtype=np.uint64).reshape(-1)
+    out = np.zeros(a.shape[0], dtype=np.uint32)
+    _check(lib().tsx_hip_mini_owner_host(k, world, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), a.shape[0],
+                                         out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+    return out
