@@ -144,7 +144,8 @@ def run_check(args, m, T, TD, dist, torch, dist_on, sharded, world, rank, red, d
             ok = ok and detail["cross"]["ok"]
         return ok, detail
     # totals: every k-mer of the reads was scanned, and the counts held by the table(s) add up to them
-    scanned = allsum(st["kmers_added"]) if (world == 1 or sharded) else None
+    # (minimizer exchange: the owners add the homopolymer totals a second time to that counter)
+    scanned = allsum(st["kmers_added"]) if ((world == 1 or sharded) and not getattr(args, "mini", False)) else None
     count_sum = allsum(st["count_sum"])
     detail["totals"] = {"kmers_in_reads": kmers_total, "scanned": scanned, "sum_of_counts_in_table": count_sum}
     ok = ok and count_sum == kmers_total and (scanned is None or scanned == kmers_total)
@@ -226,8 +227,11 @@ def main():
     ap.add_argument("--reads", type=int, default=1087000, help="synthetic reads per GPU (~1e9 k-mers at k=31)")
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--path", default="auto", choices=["auto", "atomic", "partitioned"])
-    ap.add_argument("--merge", default="shard", choices=["shard", "tables"],
-                    help="N > 1: exchange keys before the build (sharded table) or merge per-GPU tables after it")
+    ap.add_argument("--merge", default="auto", choices=["auto", "mini", "shard", "tables"],
+                    help="N > 1: mini = owner of a k-mer = f(its minimizer), masked strip descriptions travel, every GPU a whole "
+                         "table of what it owns (20 <= k <= 32, any N <= 16); shard = ONE table sharded by slot range (N a "
+                         "power of two, k <= 32); tables = per-GPU tables merged afterwards (any k); auto = mini from 4 GPUs "
+                         "on (by the one-GPU simulations of a step, DESIGN.md section 6), else shard, else tables")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL (one GPU per rank); gloo only to rehearse N > 1 on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -322,15 +326,24 @@ def main():
     # N > 1: ONE table sharded by slot range over the GPUs (2^(l + log2 N) slots in all, so the
     # load factor per GPU is the same at every N: weak scaling).  Keys travel to their owner
     # through one RCCL all-to-all before they are built; see tsxcount_amd/distributed.py.
-    sharded = dist_on and (world & (world - 1)) == 0 and args.k <= 32 and args.merge == "shard"
+    can_mini = dist_on and 20 <= args.k <= 32 and world <= 16
+    can_shard = dist_on and (world & (world - 1)) == 0 and args.k <= 32
+    mode = args.merge
+    if mode == "auto":
+        mode = "mini" if (can_mini and world >= 4) else ("shard" if can_shard else ("mini" if can_mini else "tables"))
+    if (mode == "mini" and not can_mini) or (mode == "shard" and not can_shard):
+        raise SystemExit("bench.py: --merge %s does not fit k = %d on %d GPUs" % (mode, args.k, world))
+    mini = dist_on and mode == "mini"
+    sharded = dist_on and mode == "shard"
+    args.mini = mini
     bits = world.bit_length() - 1 if sharded else 0
     m = T.TSXHashMapHIP(args.l, 0, args.k, device=local_rank, shard_bits=bits, shard_index=rank if sharded else 0)
     m.set_path(args.path)
-    sc = TD.ShardedCounter(m, nbytes) if sharded else None
+    sc = TD.ShardedCounter(m, nbytes) if sharded else (TD.MinimizerCounter(m, nbytes) if mini else None)
 
     def step():
         m.clear()
-        if sharded:
+        if sharded or mini:
             sc.step(text.data_ptr(), nbytes)
         else:
             m.countFastqDevice(text.data_ptr(), nbytes)
@@ -384,7 +397,7 @@ def main():
         # plus one build call per step -- per-step figures either way
         # (a table above 2^32 slots is built slab by slab: one timing tuple per text window and per slab, see count_slabs)
         slab_bits = max(0, args.l - 14 - 18) if (m.wk == 1 and m.layout.entry_limbs == 1 and not dist_on) else 0
-        pieces = args.steps if (sharded or slab_bits) else max(launches, 1)
+        pieces = args.steps if (sharded or mini or slab_bits) else max(launches, 1)
         partitioned = build_ms / pieces > 0.5
         keys_logged = st["distinct"] if partitioned else 0
         # algorithmic bytes of each stage of one launch: the scan kernel reads the
@@ -416,6 +429,14 @@ def main():
                                   if (flt == "1" or (flt == "auto" and world >= 4)) else "walk_part_kernel", world))
             stage_bytes["scan"] = nbytes + nbytes // 2 * 2          # text read; descriptions written and packed
             stage_bytes["level1"] = world * (nbytes // 2) + rec_b * keys_logged
+        if mini:
+            # minimizer exchange: "scan" = strip_desc_kernel + desc_owner_split_kernel of every window, "level1" = the walks over
+            # the lists this GPU was sent, then level 2 and the build
+            names["scan"] = "strip_desc_kernel + desc_owner_split_kernel"
+            names["level1"] = "walk_part_kernel (the descriptions this GPU owns, from all %d GPUs)" % world
+            lists = 16 * (sc.last.get("received_descriptions", 0))
+            stage_bytes["scan"] = nbytes + nbytes // 2 * 2 + lists       # text read; descriptions written, read, lists written
+            stage_bytes["level1"] = lists + rec_b * keys_logged
         if slab_bits:
             names["scan"] = "strip_desc_kernel + desc_pack_kernel (every text window described once)"
             names["level1"] = "walk_part_kernel with slab filter (%d slabs x all descriptions)" % (1 << slab_bits)
@@ -440,6 +461,15 @@ def main():
                 traffic = pp.get("stages", {}).get(dom) if partitioned else pp.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if mini:
+            how = (", owner of a k-mer = f(its minimizer): strip descriptions masked per owner travel by RCCL send/recv, "
+                   "every GPU walks what it owns into a table of its own")
+        elif sharded and sc._mode() == "desc":
+            how = ", table sharded by slot range, strip descriptions all-gathered over RCCL, every GPU walks all and keeps what it owns"
+        elif sharded:
+            how = ", table sharded by slot range, keys exchanged by one RCCL all-to-all per window"
+        else:
+            how = ", per-GPU tables merged over RCCL all-to-all"
         out = {
             "metric": ("k-mers/sec inserted, k=%d, Zipf-skewed synthetic reads, 1 GPU; --check pass" % args.k) if zipf else
                       "k-mers/sec inserted, k=%d, 1e9 synthetic k-mers, 1/2/4/8 GPU; --check pass" % args.k,
@@ -454,10 +484,7 @@ def main():
                                    % (args.reads, kmers_rank, args.k, args.l,
                                       "partitioned" if partitioned else "atomic",
                                       (", built in %d slabs of 2^32 slots" % (1 << slab_bits)) if slab_bits else "",
-                                      ((", table sharded by slot range, strip descriptions all-gathered over RCCL, every GPU walks all and keeps what it owns"
-                                        if sc._mode() == "desc" else
-                                        ", table sharded by slot range, keys exchanged by one RCCL all-to-all per window") if sharded
-                                       else ", per-GPU tables merged over RCCL all-to-all") if world > 1 else ""),
+                                      how if world > 1 else ""),
                        "k": args.k, "l": args.l, "kmers_per_gpu": kmers_rank, "fastq_bytes_per_gpu": nbytes,
                        "distinct_rank0": st["distinct"], "check": "pass" if check_ok else "FAIL",
                        "check_detail": check_detail},

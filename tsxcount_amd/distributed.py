@@ -692,17 +692,14 @@ class MinimizerCounter:
                     outs.append(self.recv[i][2 * at:2 * (at + rs[p])])
                     at += rs[p]
                 inps = [self.dsc[b][2 * p * self.cap:2 * (p * self.cap + mine[p])] for p in range(world)]
-                if world > 1:
-                    comm.all_to_all_lists(outs, inps)
-                else:
-                    outs[0].copy_(inps[0])
+                comm.all_to_all_lists(outs, inps)
                 self.ev_exch[b].record(self.xs)
             n_recv_total += n_recv
             n_sent += sum(mine) - mine[rank]
             self.cs.wait_event(self.ev_exch[b])
             if i == 0:
-                # k-mer occurrences this rank will own: its share of everybody's text (a description stands for about 9)
-                est_total = int(max(n_recv, 4096) * 16 * nwin * 1.1) + 65536
+                # k-mer occurrences this rank will own: its share of everybody's text (a description stands for about 7)
+                est_total = int(max(n_recv, 4096) * 10 * nwin * 1.2) + 65536
             if late is None:
                 rc = L.tsx_hip_shard_walk_device(m.handle, vp(self.recv[i].data_ptr()), n_recv, 2, i, nwin, est_total,
                                                  vp(self.emit[1:].data_ptr()), vp(self.cs.cuda_stream))
