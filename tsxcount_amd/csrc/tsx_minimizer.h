@@ -4,7 +4,7 @@
 // key travels (8 B per occurrence) or every GPU rolls over every GPU's text (description exchange: N x the walk).  Here the
 // owner of a k-mer is a function of its MINIMIZER -- the m-mer of the k-mer with the smallest hash, m = min(11, k - 15) --
 // so runs of consecutive k-mers (about (k - m + 2) / 2 of them) share an owner: what travels is strip descriptions masked
-// per owner, 16 bytes per (strip, owner present in it), about 2.3 per strip of 16 starts, and every GPU walks only what it
+// per owner, 16 bytes per (strip, owner present in it), about 1.7 per strip of 16 starts at 8 GPUs, and every GPU walks only what it
 // owns into a table of its own (no slot-range split, no merge; a lookup goes to mz_owner_of_kmer(kmer)).
 //
 //   desc_owner_split_kernel   strip descriptions (strip_desc_kernel's wave regions) -> one packed list per owner GPU
@@ -22,8 +22,8 @@ constexpr uint32_t MZ_SALT = 0x2B5A3Du;    //   the ORDER of its values is the m
 constexpr uint32_t MZ_MULT2 = 0xC2B2AFu;   // owner = a middle slice of (value * MZ_MULT2), scaled to the number of GPUs
 constexpr int MZ_MAX_RANKS = 16;
 constexpr uint32_t MZ_CHUNK = 64;          // an owner's list is made of chunks of this many places: chunk j * G + g is workgroup g's j-th
-constexpr int MZ_NT = 256;
-constexpr int MZ_WG_PER_CU = 4;
+constexpr int MZ_NT = 1024;               // one workgroup of 1024 per CU: a list is as long as its busiest workgroup made it, and the
+constexpr int MZ_WG_PER_CU = 1;           //   shares of 256 big workgroups vary less than those of 1024 small ones (5 % holes instead of 11 %)
 constexpr int MZ_ROUND = 4;                // owners of a strip placed per round (more: another round)
 static_assert(MZ_NT % (int)MZ_CHUNK == 0, "the hole filler takes whole chunks");
 
@@ -52,7 +52,7 @@ __host__ __device__ inline uint32_t mz_owner_of_kmer(uint64_t x, uint32_t k, uin
     return mz_owner(best, mbits, nranks);
 }
 
-__global__ __launch_bounds__(MZ_NT, 4) void desc_owner_split_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
+__global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
                                                                     const unsigned long long *desc_cnt, uint32_t nregions,
                                                                     uint32_t nranks, uint4 *out, uint64_t out_cap,
                                                                     uint32_t *used, unsigned long long *hom_cnt, int merge) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(MZ_NT, 4) void desc_owner_split_kernel(TableParams 
     lds_barrier();
     // mz_key of the m-mer at `bit` of (lo, hi); pa: bit 2j of it = the m-mer at base j of lo starts or ends with AAA
     auto keyat = [&](uint32_t lo, uint32_t hi, uint32_t pa, uint32_t bit) -> uint32_t {
-        const uint32_t x = __funnelshift_r(lo, hi, bit) & mmask;
+        const uint32_t x = __funnelshift_r(lo, hi, bit);   // (what lies above the m-mer only reaches product bits >= 2m)
         const uint32_t v = ((__umul24(x, MZ_MULT) + MZ_SALT) & mmask) << sh;
         return v | ((pa << (31u - bit)) & 0x80000000u);
     };

@@ -648,8 +648,12 @@ __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const u
                                                             uint64_t *dst, uint64_t dst_cap, unsigned long long *dst_cnt,
                                                             uint32_t nb, uint32_t shift, uint64_t *ovq_all,
                                                             uint32_t *ovq_cnt, uint32_t ovq_cap, uint64_t n_packed,
-                                                            uint32_t dst_g0, uint32_t dst_gtot, int own_only,
+                                                            uint32_t dst_g0, uint32_t dst_gtot, int own_flags,
                                                             unsigned long long *emit_sum, int long_desc, uint32_t flush_q) {
+    // own_flags: low two bits = 0 local run, 1 keep only the keys this shard owns, 2 minimizer exchange (below); 4 = this launch
+    // APPENDS to the sub-lists and the overflow queue an earlier launch of the same step left (windows of a sharded step)
+    const int own_only = own_flags & 3;
+    const bool append = (own_flags & 4) != 0;
     constexpr int HOT_N = 8;
     __shared__ uint64_t s_hot_key[(NT / 64) * HOT_N];
     __shared__ uint32_t s_hot_cnt[(NT / 64) * HOT_N];
@@ -693,8 +697,8 @@ __global__ __launch_bounds__(NT, 4) void walk_part_kernel(TableParams p, const u
     if (tid < (NT / 64) * HOT_N) { s_hot_key[tid] = 0; s_hot_cnt[tid] = 0; }
     if (tid < OVF_N) { s_ovk[tid] = 0; s_ovc[tid] = 0; }
     if (tid < 2) s_njobs[tid] = 0;
-    if (tid == 0) s_ovn = 0;
-    for (uint32_t b = tid; b < nb; b += NT) { s_cur[b] = 0; s_th[b] = 0; }
+    if (tid == 0) s_ovn = (append && ovq_cnt) ? ovq_cnt[blockIdx.x] : 0u;
+    for (uint32_t b = tid; b < nb; b += NT) { s_cur[b] = append ? (uint32_t)dst_cnt[(uint64_t)b * dst_gtot + dst_g0 + blockIdx.x] : 0u; s_th[b] = 0; }
     uint64_t *ovq = ovq_all ? ovq_all + (size_t)blockIdx.x * ovq_cap : nullptr;
     unsigned long long added = 0;   // (k-mers are counted by strip_desc_kernel)
     unsigned long long emitted = 0; // sharded runs: k-mer occurrences this GPU kept (sum over GPUs == k-mers scanned)

@@ -1519,8 +1519,9 @@ extern "C" int tsx_hip_mini_supported(tsx_hip_map *m) {
 
 extern "C" int tsx_hip_mini_capacity(tsx_hip_map *m, size_t text_bytes, int nranks, size_t *descs_per_owner_out) {
     if (!m || !descs_per_owner_out || nranks < 1 || nranks > MZ_MAX_RANKS) return TSX_HIP_EINVAL;
-    // a strip of 16 start positions yields at most one description per owner; every workgroup may leave one chunk open
-    *descs_per_owner_out = text_bytes / 16 + 4096 + (size_t)2 * MZ_CHUNK * (size_t)m->cus * MZ_WG_PER_CU;
+    // a strip of 16 start positions yields at most one description per owner, + one for a run it shares with its neighbour;
+    // every workgroup may leave a chunk open, and a list is as long as its busiest workgroup made it
+    *descs_per_owner_out = text_bytes / 8 + 4096 + (size_t)2 * MZ_CHUNK * (size_t)m->cus * MZ_WG_PER_CU;
     return TSX_HIP_OK;
 }
 
@@ -1566,12 +1567,20 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     hipStream_t st = pick_stream(m, stream);
     if (!m->sh_pl) m->sh_pl = new PartPlan();
     PartPlan &pl = *m->sh_pl;
-    if (slot == 0) {
+    // long_desc & 2: what the minimizer exchange sent to a map with shard_bits = 0 -- every key stays, homopolymers were
+    // taken out by the sender, about half of a description's 16 positions are valid (a flush every second quarter), and
+    // the windows of a step APPEND to one set of level-1 sub-lists (level 2 then reads as many pieces as on one GPU)
+    const bool mini = (long_desc & 2) != 0;
+    long_desc &= 1;
+    if (mini && m->p.lg != m->p.l) return TSX_HIP_EINVAL;
+    const uint32_t caller_slots = nslots, caller_slot = slot;
+    if (mini) { nslots = 1; slot = 0; }
+    if (caller_slot == 0) {
         // lists per slot: two workgroups per CU while the pieces of a bucket stay within what a level-2 workgroup walks
         uint32_t gw = (uint32_t)m->cus * 2;
         while (gw > 32 && (uint64_t)gw * nslots > (uint64_t)PART_MAX_PIECES * level2_cpr(m)) gw /= 2;
         m->sh_rw = gw;
-        m->sh_windows = nslots;
+        m->sh_windows = caller_slots;
         const int g1 = (int)(gw * nslots);
         const uint64_t maxrec = est_total_keys + 65536;
         std::swap(m->d_buf[1], m->sh_buf1); std::swap(m->buf_bytes[1], m->sh_buf1_bytes);
@@ -1588,10 +1597,10 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
         rc = ensure_ovq(m, (size_t)nq2 + pl.G1, pl.rw, st);
         if (rc != TSX_HIP_OK) return rc;
         HIP_TRY(hipMemsetAsync(m->d_ovq_cnt, 0, ((size_t)nq2 + pl.G1) * 4, st));
-    } else if (m->sh_windows != nslots || !pl.fused) {
+    } else if (m->sh_windows != caller_slots || !pl.fused) {
         return TSX_HIP_EINVAL;
     }
-    if (slot == 0 && m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
+    if (caller_slot == 0 && m->timing && !m->ev_open.empty() && (size_t)m->ev_open.front() + EV_N <= m->ev_used) {
         HIP_TRY(hipEventRecord(m->ev[(size_t)m->ev_open.front() + 3], st));   // "level 1" = the walks, up to the start of level 2
         m->sh_ev3 = true;
     }
@@ -1601,14 +1610,8 @@ extern "C" int tsx_hip_shard_walk_device(tsx_hip_map *m, const void *dev_desc, s
     // this GPU keeps one key in 2^shard_bits: a ring flush every 1, 2 or 4 quarter strips (walk_part_kernel)
     const uint32_t nown = 1u << (m->p.lg - m->p.l);
     uint32_t flush_q = nown >= 4 ? 4u : (nown == 2 ? 2u : 1u);
-    // long_desc & 2: what the minimizer exchange sent to a map with shard_bits = 0 -- every key stays, homopolymers were
-    // taken out by the sender, about half of a description's 16 positions are valid (a flush every second quarter)
-    const int own_mode = (long_desc & 2) ? 2 : 1;
-    if (own_mode == 2) {
-        if (nown != 1) return TSX_HIP_EINVAL;
-        flush_q = 2u;
-    }
-    long_desc &= 1;
+    const int own_mode = mini ? (2 | (caller_slot > 0 ? 4 : 0)) : 1;
+    if (mini) flush_q = 2u;
     if (const char *e = getenv("TSX_HIP_WALK_FLUSHQ")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) flush_q = (uint32_t)v; }
     TableParams pp = m->p;
     pp.defer = DeferList{m->d_def_rec, m->d_def_cnt, m->d_def_n, (uint64_t)m->def_cap};
