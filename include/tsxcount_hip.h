@@ -328,6 +328,15 @@ int tsx_hip_mini_capacity(tsx_hip_map *m, size_t text_bytes, int nranks, size_t 
 int tsx_hip_mini_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off, size_t win_len,
                                int nranks, void *dev_desc, size_t cap_per_owner, void *dev_counts, void *dev_kmer_sum,
                                void *stream);
+/* The same in two steps, for a step of several exchange windows: the text is described ONCE (line pass + strip descriptions,
+ * kept in the map's scratch until the next describe), then split share by share -- share `part` of `nparts` of the described
+ * strips, lists and counts as above, cap_per_owner >= tsx_hip_mini_part_capacity(len, nparts) -- so that the exchange of one
+ * share runs while the next is split and the one before is walked.  dev_kmer_sum += all k-mer occurrences of the text. */
+int tsx_hip_mini_part_capacity(tsx_hip_map *m, size_t text_bytes, uint32_t nparts, size_t *descs_per_owner_out);
+int tsx_hip_mini_describe_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t off, size_t len, void *dev_kmer_sum,
+                                 void *stream);
+int tsx_hip_mini_split_device(tsx_hip_map *m, uint32_t part, uint32_t nparts, int nranks, void *dev_desc, size_t cap_per_owner,
+                              void *dev_counts, void *stream);
 int tsx_hip_mini_owner_host(int k, int nranks, const uint64_t *kmers, size_t n, uint32_t *owners_out);
 
 

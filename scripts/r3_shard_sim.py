@@ -20,19 +20,17 @@ T.synth_fastq_device(seed, 0, reads, k, buf.data_ptr(), nb)
 m = T.TSXHashMapHIP(l, 0, k)
 L, vp = m._lib, ctypes.c_void_p
 assert L.tsx_hip_mini_supported(m.handle)
-cap = ctypes.c_size_t(0)
-L.tsx_hip_mini_capacity(m.handle, nb + 256, world, ctypes.byref(cap))
-cap = cap.value
 i64 = dict(dtype=torch.int64, device="cuda:0")
-dsc = torch.empty((2 * cap * world,), **i64)
 cnt = torch.zeros((world + 4,), **i64)
 emit = torch.zeros((2,), **i64)
 hom_k = torch.from_numpy(np.stack([T.encode("ACGT"[b] * k, k) for b in range(4)]).astype(np.int64)).to("cuda:0")
 
 
 nwin = int(os.environ.get("SIM_WINDOWS", "4"))
-win = ((nb + nwin - 1) // nwin + 4095) // 4096 * 4096
-L.tsx_hip_mini_capacity(m.handle, win + 256, world, ctypes.byref(ctypes.c_size_t(0)))
+pc = ctypes.c_size_t(0)
+L.tsx_hip_mini_part_capacity(m.handle, nb + 256, nwin, ctypes.byref(pc))
+cap = pc.value
+dsc = torch.empty((2 * cap * world,), **i64)
 recv = [torch.empty((2 * cap * (world if reads < 100000 else 1),), **i64) for _ in range(nwin)]      # what the all-to-all of a window would deliver: N lists back to back
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nwin)]
 copy_ms = []
@@ -49,11 +47,10 @@ def step_on(cs):
     emit.zero_()
     tot = [0] * (world + 4)
     ms = 0.0
+    rc = L.tsx_hip_mini_describe_device(m.handle, vp(buf.data_ptr()), nb, 0, nb, vp(emit.data_ptr()), cs)   # the text is described once
+    assert rc == 0, rc
     for i in range(nwin):
-        off = min(i * win, nb // 16 * 16)
-        ln = max(0, min(win, nb - off))
-        rc = L.tsx_hip_mini_window_device(m.handle, vp(buf.data_ptr()), nb, off, ln, world, vp(dsc.data_ptr()), cap,
-                                          vp(cnt.data_ptr()), vp(emit.data_ptr()), cs)
+        rc = L.tsx_hip_mini_split_device(m.handle, i, nwin, world, vp(dsc.data_ptr()), cap, vp(cnt.data_ptr()), cs)
         assert rc == 0, rc
         c = [int(x) for x in cnt.tolist()]
         assert max(c[:world]) <= cap and 2 * sum(c[:world]) <= recv[i].numel()

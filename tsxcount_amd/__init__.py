@@ -93,6 +93,9 @@ def lib():
     L.tsx_hip_mini_supported.argtypes = [vp]
     L.tsx_hip_mini_capacity.argtypes = [vp, sz, ctypes.c_int, ctypes.POINTER(sz)]
     L.tsx_hip_mini_window_device.argtypes = [vp, vp, sz, sz, sz, ctypes.c_int, vp, sz, vp, vp, vp]
+    L.tsx_hip_mini_part_capacity.argtypes = [vp, sz, ctypes.c_uint32, ctypes.POINTER(sz)]
+    L.tsx_hip_mini_describe_device.argtypes = [vp, vp, sz, sz, sz, vp, vp]
+    L.tsx_hip_mini_split_device.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, vp, sz, vp, vp]
     L.tsx_hip_mini_owner_host.argtypes = [ci, ci, u64p, sz, ctypes.POINTER(ctypes.c_uint32)]
     L.tsx_hip_destroy.argtypes = [vp]
     L.tsx_hip_destroy.restype = None

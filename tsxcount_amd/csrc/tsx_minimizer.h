@@ -55,7 +55,8 @@ __host__ __device__ inline uint32_t mz_owner_of_kmer(uint64_t x, uint32_t k, uin
 __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
                                                                     const unsigned long long *desc_cnt, uint32_t nregions,
                                                                     uint32_t nranks, uint4 *out, uint64_t out_cap,
-                                                                    uint32_t *used, unsigned long long *hom_cnt, int merge) {
+                                                                    uint32_t *used, unsigned long long *hom_cnt, int merge,
+                                                                    uint32_t part, uint32_t nparts) {
     __shared__ uint32_t s_cnt[MZ_MAX_RANKS];    // descriptions of this round per owner
     __shared__ uint32_t s_base[MZ_MAX_RANKS];   // descriptions of this workgroup for the owner before this round
     __shared__ uint32_t s_fill[MZ_MAX_RANKS];   //   ... including it
@@ -80,8 +81,11 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
         return ((unsigned long long)(n / MZ_CHUNK) * G + g) * MZ_CHUNK + (n % MZ_CHUNK);
     };
     for (uint32_t r = g; r < nregions; r += G) {
-        const uint32_t nr = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
-        const uint4 *rd = desc + (uint64_t)r * desc_cap;
+        // share `part` of `nparts` of every region (a text is described once and split window by window: the exchange of
+        // one window runs while the next is split and the one before is walked)
+        const uint32_t nall = (uint32_t)min((uint64_t)desc_cnt[r], desc_cap);
+        const uint32_t lo = (uint32_t)((uint64_t)nall * part / nparts), nr = (uint32_t)((uint64_t)nall * (part + 1u) / nparts) - lo;
+        const uint4 *rd = desc + (uint64_t)r * desc_cap + lo;
         uint4 dn = make_uint4(0, 0, 0, 0);
         if (tid < nr) dn = rd[tid];
         for (uint32_t base = 0; base < nr; base += MZ_NT) {

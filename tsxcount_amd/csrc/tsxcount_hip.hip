@@ -96,6 +96,7 @@ struct tsx_hip_map {
     std::vector<unsigned long long> h_regions;   // host copy of the region table of a sharded build (starts, then sizes)
     PartPlan *sh_pl = nullptr;                   // sharded run, level 1 per exchange window: the plan made at window 0,
     uint32_t sh_rw = 0, sh_windows = 0;          // regions per window, windows of the step,
+    uint32_t mz_regions = 0; uint64_t mz_dcap = 0; size_t mz_len = 0;   // minimizer exchange: the described text waiting in buffer 1 (regions x capacity; its bytes)
     bool sh_ev3 = false;                         // stage timing: the walks of a description exchange have recorded event 3
     unsigned long long *d_desc_cnt = nullptr;    // strips described per wave of strip_desc_kernel (key log form)
     size_t desc_cnt_entries = 0;
@@ -1033,6 +1034,7 @@ struct ShardOut {
 // owners > 0 (minimizer exchange): one packed list per owner GPU at out + o * cap, count[0 .. owners) their lengths,
 // count[owners .. owners + 4) the homopolymer k-mer occurrences taken out of the descriptions, per base.
 struct DescOut { uint4 *out = nullptr; uint64_t cap = 0; unsigned long long *count = nullptr, *sum = nullptr; int long_desc = 0; int owners = 0; };
+// (owners != 0: describe only -- the wave regions stay in buffer 1 for mini_split)
 
 static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, uint64_t own_end, int head_open,
                            hipStream_t st, ShardOut sh = ShardOut(), HotOut hot = HotOut(), DescOut dsc = DescOut()) {
@@ -1067,7 +1069,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
                            (const uint32_t *)chunk);
     }
     if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-    if (dsc.out) {
+    if (dsc.out || dsc.owners) {
         const int gdd = (int)std::min<uint64_t>(ntiles, (uint64_t)m->cus * 8), gdr = gdd * (NT / 64);
         const uint32_t du = dsc.long_desc ? 2u : 1u;   // 16-byte units per description (long: four strips in 32 bytes)
         const uint64_t dcap = ((ntiles + gdd - 1) / gdd) * (dsc.long_desc ? 16 : 64);
@@ -1082,17 +1084,9 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         unsigned long long *d_cnt = m->d_desc_cnt, *d_offs = d_cnt + gdr, *d_tot = d_offs + gdr;
         hipLaunchKernelGGL(strip_desc_kernel, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum, dsc.long_desc);
-        if (dsc.owners) {   // owner = f(minimizer): split the wave regions into one packed list per owner
-            static const int mz_wgs = getenv("TSX_HIP_MZ_WGS") ? std::min(MZ_WG_PER_CU, std::max(1, atoi(getenv("TSX_HIP_MZ_WGS")))) : MZ_WG_PER_CU;
-            static const int mz_merge = getenv("TSX_HIP_MZ_MERGE") ? atoi(getenv("TSX_HIP_MZ_MERGE")) : 1;
-            const int gsp = std::min(gdr, m->cus * mz_wgs);
-            uint32_t *d_used = (uint32_t *)(d_tot + 8);   // chunks taken per (owner, workgroup)
-            hipLaunchKernelGGL(desc_owner_split_kernel, dim3(gsp), dim3(MZ_NT), 0, st, m->p, (const uint4 *)m->d_buf[1], dcap,
-                               (const unsigned long long *)d_cnt, (uint32_t)gdr, (uint32_t)dsc.owners, dsc.out,
-                               (uint64_t)dsc.cap, d_used, dsc.count + dsc.owners, mz_merge);
-            hipLaunchKernelGGL(desc_owner_finish_kernel, dim3(64, dsc.owners), dim3(MZ_NT), 0, st, (const uint32_t *)d_used,
-                               (uint32_t)gsp, (uint32_t)dsc.owners, dsc.out, (uint64_t)dsc.cap, dsc.count, m->p.stats);
+        if (dsc.owners) {   // owner = f(minimizer): the regions stay where they are, mini_split hands them out by owner
             HIP_TRY(hipGetLastError());
+            m->mz_regions = (uint32_t)gdr; m->mz_dcap = dcap;
             if (ev) {
                 for (int i = 2; i < EV_N; ++i) HIP_TRY(hipEventRecord(ev[i], st));
                 m->ev_open.push_back((long)(ev - m->ev.data()));
@@ -1517,12 +1511,74 @@ extern "C" int tsx_hip_mini_supported(tsx_hip_map *m) {
     return (m && tsx_hip_shard_l1_supported(m) && m->p.lg == m->p.l && mz_supported((uint32_t)m->p.k)) ? 1 : 0;
 }
 
+// descriptions one owner's list may take when a text of text_bytes is described at once and split in nparts shares: a
+// strip of 16 start positions yields at most one description per owner, + one for a run it shares with its neighbour; a
+// region's share rounds up; every workgroup may leave a chunk open, and a list is as long as its busiest workgroup made it
+static size_t mini_part_cap(const tsx_hip_map *m, size_t text_bytes, uint32_t nparts) {
+    return text_bytes / 8 / nparts + 65536 + 4096 + (size_t)2 * MZ_CHUNK * (size_t)m->cus * MZ_WG_PER_CU;
+}
+extern "C" int tsx_hip_mini_part_capacity(tsx_hip_map *m, size_t text_bytes, uint32_t nparts, size_t *descs_per_owner_out) {
+    if (!m || !descs_per_owner_out || nparts == 0) return TSX_HIP_EINVAL;
+    *descs_per_owner_out = mini_part_cap(m, text_bytes, nparts);
+    return TSX_HIP_OK;
+}
 extern "C" int tsx_hip_mini_capacity(tsx_hip_map *m, size_t text_bytes, int nranks, size_t *descs_per_owner_out) {
     if (!m || !descs_per_owner_out || nranks < 1 || nranks > MZ_MAX_RANKS) return TSX_HIP_EINVAL;
-    // a strip of 16 start positions yields at most one description per owner, + one for a run it shares with its neighbour;
-    // every workgroup may leave a chunk open, and a list is as long as its busiest workgroup made it
-    *descs_per_owner_out = text_bytes / 8 + 4096 + (size_t)2 * MZ_CHUNK * (size_t)m->cus * MZ_WG_PER_CU;
+    *descs_per_owner_out = mini_part_cap(m, text_bytes, 1);
     return TSX_HIP_OK;
+}
+
+// share `part` of `nparts` of the described text -> one packed list per owner
+static int mini_split(tsx_hip_map *m, uint32_t part, uint32_t nparts, int nranks, void *dev_desc, size_t cap_per_owner,
+                      void *dev_counts, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(dev_counts, 0, ((size_t)nranks + 4) * 8, st));
+    if (m->mz_regions == 0) return TSX_HIP_OK;   // an empty text
+    static const int mz_wgs = getenv("TSX_HIP_MZ_WGS") ? std::min(MZ_WG_PER_CU, std::max(1, atoi(getenv("TSX_HIP_MZ_WGS")))) : MZ_WG_PER_CU;
+    static const int mz_merge = getenv("TSX_HIP_MZ_MERGE") ? atoi(getenv("TSX_HIP_MZ_MERGE")) : 1;
+    const int gdr = (int)m->mz_regions, gsp = std::min(gdr, m->cus * mz_wgs);
+    unsigned long long *d_cnt = m->d_desc_cnt, *count = (unsigned long long *)dev_counts;
+    uint32_t *d_used = (uint32_t *)(d_cnt + 2 * (size_t)gdr + 8);   // chunks taken per (owner, workgroup)
+    hipLaunchKernelGGL(desc_owner_split_kernel, dim3(gsp), dim3(MZ_NT), 0, st, m->p, (const uint4 *)m->d_buf[1], m->mz_dcap,
+                       (const unsigned long long *)d_cnt, (uint32_t)gdr, (uint32_t)nranks, (uint4 *)dev_desc, (uint64_t)cap_per_owner,
+                       d_used, count + nranks, mz_merge, part, nparts);
+    hipLaunchKernelGGL(desc_owner_finish_kernel, dim3(64, nranks), dim3(MZ_NT), 0, st, (const uint32_t *)d_used, (uint32_t)gsp,
+                       (uint32_t)nranks, (uint4 *)dev_desc, (uint64_t)cap_per_owner, count, m->p.stats);
+    HIP_TRY(hipGetLastError());
+    return TSX_HIP_OK;
+}
+
+static int mini_describe(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t off, size_t len, void *dev_kmer_sum,
+                         hipStream_t st) {
+    if (off == 0) HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
+    m->mz_regions = 0; m->mz_len = len;
+    if (len == 0) return TSX_HIP_OK;
+    DescOut dsc;
+    dsc.sum = (unsigned long long *)dev_kmer_sum;
+    dsc.owners = 1;
+    const size_t halo = (size_t)m->p.k - 1;
+    const size_t ext = std::min(len + halo, n_total - off);
+    return run_fastq_piece(m, (const uint8_t *)dev_text + off, ext, len, off ? -1 : 0, st, ShardOut(), HotOut(), dsc);
+}
+
+extern "C" int tsx_hip_mini_describe_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t off, size_t len,
+                                            void *dev_kmer_sum, void *stream) {
+    if (!m || (!dev_text && n_total) || ((uintptr_t)dev_text & 15) || (off & 15) || off > n_total || len > n_total - off)
+        return TSX_HIP_EINVAL;
+    if (!tsx_hip_mini_supported(m)) return TSX_HIP_EINVAL;
+    if (len >= ((size_t)4 << 30)) return TSX_HIP_ERANGE;
+    HIP_TRY(hipSetDevice(m->device));
+    return mini_describe(m, dev_text, n_total, off, len, dev_kmer_sum, pick_stream(m, stream));
+}
+
+extern "C" int tsx_hip_mini_split_device(tsx_hip_map *m, uint32_t part, uint32_t nparts, int nranks, void *dev_desc,
+                                         size_t cap_per_owner, void *dev_counts, void *stream) {
+    if (!m || nparts == 0 || part >= nparts || !dev_desc || ((uintptr_t)dev_desc & 15) || !dev_counts || nranks < 1 ||
+        nranks > MZ_MAX_RANKS)
+        return TSX_HIP_EINVAL;
+    if (!tsx_hip_mini_supported(m)) return TSX_HIP_EINVAL;
+    if (m->mz_regions && cap_per_owner < mini_part_cap(m, m->mz_len, nparts)) return TSX_HIP_ERANGE;
+    HIP_TRY(hipSetDevice(m->device));
+    return mini_split(m, part, nparts, nranks, dev_desc, cap_per_owner, dev_counts, pick_stream(m, stream));
 }
 
 extern "C" int tsx_hip_mini_window_device(tsx_hip_map *m, const void *dev_text, size_t n_total, size_t win_off, size_t win_len,
@@ -1538,16 +1594,9 @@ extern "C" int tsx_hip_mini_window_device(tsx_hip_map *m, const void *dev_text, 
     if (cap_per_owner < need) return TSX_HIP_ERANGE;
     HIP_TRY(hipSetDevice(m->device));
     hipStream_t st = pick_stream(m, stream);
-    if (win_off == 0) HIP_TRY(hipMemsetAsync(m->d_carry, 0, 64, st));
-    HIP_TRY(hipMemsetAsync(dev_counts, 0, ((size_t)nranks + 4) * 8, st));
-    if (win_len == 0) return TSX_HIP_OK;
-    DescOut dsc;
-    dsc.out = (uint4 *)dev_desc; dsc.cap = cap_per_owner; dsc.count = (unsigned long long *)dev_counts;
-    dsc.sum = (unsigned long long *)dev_kmer_sum;
-    dsc.owners = nranks;
-    const size_t halo = (size_t)m->p.k - 1;
-    const size_t len = std::min(win_len + halo, n_total - win_off);
-    return run_fastq_piece(m, (const uint8_t *)dev_text + win_off, len, win_len, win_off ? -1 : 0, st, ShardOut(), HotOut(), dsc);
+    int rc = mini_describe(m, dev_text, n_total, win_off, win_len, dev_kmer_sum, st);
+    if (rc != TSX_HIP_OK) return rc;
+    return mini_split(m, 0, 1, nranks, dev_desc, cap_per_owner, dev_counts, st);
 }
 
 extern "C" int tsx_hip_mini_owner_host(int k, int nranks, const uint64_t *kmers, size_t n, uint32_t *owners_out) {

@@ -588,9 +588,10 @@ class MinimizerCounter:
         compute stream   split(0) split(1) walk(0) split(2) walk(1) ...  walk(W-1)  level 2 + build + homopolymers
         exchange stream        sizes(0) a2a(0)   sizes(1) a2a(1) ...
 
-    split(i)  tsx_hip_mini_window_device: window i -> strip descriptions, one packed list per owner rank (consecutive
-              k-mers mostly share a minimizer, so a strip of 16 starts ends up in about 1.8 lists); homopolymer k-mers
-              (poly-A tails: ONE key, one owner) are counted here instead and leave the descriptions
+    split(i)  the text is described ONCE (tsx_hip_mini_describe_device: line pass + strip descriptions; texts above 2 GiB in
+              pieces); tsx_hip_mini_split_device then hands out share i of the described strips as one packed list per owner
+              rank (consecutive k-mers mostly share a minimizer, so a strip of 16 starts ends up in about 1.7 lists);
+              homopolymer k-mers (poly-A tails: ONE key, one owner) are counted here instead and leave the descriptions
     sizes(i)  one small all-to-all: per pair {descriptions to come, the sender's status}; the only host wait of the window,
               while split(i+1) is already queued
     a2a(i)    grouped send / recv straight from the lists into window i's receive buffer (back to back by source rank)
@@ -601,6 +602,7 @@ class MinimizerCounter:
     Integrity: sum over ranks of (k-mer occurrences described - walked - homopolymers) must be 0."""
 
     MIN_WINDOW = 32 << 20
+    PIECE = 2 << 30          # bytes of text described at once (the entry point takes less than 4 GiB)
 
     def __init__(self, hmap, max_text_bytes, group=None, windows=None):
         from . import _check
@@ -614,9 +616,14 @@ class MinimizerCounter:
             raise ValueError("minimizer exchange: at most 16 ranks")
         self.dev = torch.device("cuda", hmap.device)
         self.max_text_bytes = agreed_max(max_text_bytes, self.comm, self.dev)
-        self.windows, self.win_bytes = window_geometry(self.max_text_bytes, windows, self.MIN_WINDOW)
+        # a text is described in pieces of at most PIECE bytes (one line pass + one strip_desc_kernel launch each); every piece
+        # is split and exchanged in `parts` shares.  Every rank runs pieces x parts rounds of collectives, whatever its own text.
+        self.piece_bytes = min(self.PIECE, max(4096, (self.max_text_bytes + 4095) & ~4095))
+        self.pieces = max(1, -(-self.max_text_bytes // self.piece_bytes))
+        self.parts, _ = window_geometry(self.piece_bytes, windows, self.MIN_WINDOW)
+        self.windows = self.pieces * self.parts
         cap = ctypes.c_size_t(0)
-        _check(L.tsx_hip_mini_capacity(hmap.handle, self.win_bytes + 256, self.world, ctypes.byref(cap)))
+        _check(L.tsx_hip_mini_part_capacity(hmap.handle, self.piece_bytes + 256, self.parts, ctypes.byref(cap)))
         self.cap = cap.value
         i64 = dict(dtype=torch.int64, device=self.dev)
         self.dsc = [torch.empty((2 * self.cap * self.world,), **i64) for _ in range(2)]     # [owner][cap] descriptions of 16 bytes
@@ -651,10 +658,15 @@ class MinimizerCounter:
 
         def split(i):
             b = i & 1
-            off, ln = window_of(i, nbytes, self.win_bytes)
-            rc = L.tsx_hip_mini_window_device(m.handle, vp(text_ptr), nbytes, off, ln, world, vp(self.dsc[b].data_ptr()),
-                                              self.cap, vp(self.cnt[b].data_ptr()), vp(self.emit.data_ptr()),
-                                              vp(self.cs.cuda_stream))
+            piece, part = divmod(i, self.parts)
+            rc = OK
+            if part == 0:     # the piece is described once; its shares follow window by window
+                off, ln = window_of(piece, nbytes, self.piece_bytes)
+                rc = L.tsx_hip_mini_describe_device(m.handle, vp(text_ptr), nbytes, off, ln, vp(self.emit.data_ptr()),
+                                                    vp(self.cs.cuda_stream))
+            rc2 = L.tsx_hip_mini_split_device(m.handle, part, self.parts, world, vp(self.dsc[b].data_ptr()), self.cap,
+                                              vp(self.cnt[b].data_ptr()), vp(self.cs.cuda_stream))
+            rc = rc if rc != OK else rc2
             with torch.cuda.stream(self.cs):
                 self.hom += self.cnt[b][world:]
             self.ev_scan[b].record(self.cs)
