@@ -176,6 +176,19 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
     uint8_t *o = out + out_off[mem];
     const uint32_t olen = out_len[mem];
     uint32_t pos = 0, err = INF_OK;
+    // Literals wait in a register, eight to a store: s_waitcnt counts stores as well as loads, so an iteration that
+    // stored a byte made the next one wait for that store to land -- a memory round trip per literal.  o[pos - lcnt ..
+    // pos) is what waits in lbuf; it is stored before anything reads the output (a match, the CRC) and at the end of
+    // a block.  A store of fewer than eight literals writes eight bytes all the same (zeros behind them, in places of
+    // this member that later output overwrites), byte by byte only at the very end of the member.
+    uint64_t lbuf = 0;
+    uint32_t lcnt = 0;
+    auto lflush = [&]() {
+        if (lcnt == 0u) return;
+        if (pos - lcnt + 8u <= olen) __builtin_memcpy(o + pos - lcnt, &lbuf, 8);
+        else for (uint32_t i = 0; i < lcnt; ++i) o[pos - lcnt + i] = (uint8_t)(lbuf >> (8u * i));
+        lbuf = 0; lcnt = 0;
+    };
     // every loop below either consumes input bits or produces output bytes; `budget` bounds the whole member
     // anyway (a corrupt stream must never keep a wave alive)
     uint32_t budget = olen + 8u * in_len[mem] + 1024u;
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
         const uint32_t type = b.get(2);
         if (b.fail) { err = INF_ETRUNC; break; }
         if (type == 0) {   // stored: skip to the byte boundary, LEN, NLEN, LEN bytes
+            lflush();
             b.used(b.cnt & 7u);
             b.buf >>= (b.cnt & 7u);
             b.cnt &= ~7u;
@@ -288,6 +302,7 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
                     const uint32_t dist = dbase + b.get(dext);
                     if (b.fail) { err = INF_ETRUNC; break; }
                     if (dist > pos || pos + len > olen) { err = INF_EOUTPUT; break; }
+                    lflush();   // (no copy is in flight here: the last one landed in B before the literals were decoded)
                     clen = len;
                     cdist = dist;
                     have_pat = false;
@@ -310,7 +325,9 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
             const bool small = cdist < 8u;
             uint32_t todo = 0;   // 1: load for a copy of 8 bytes, 2: load of the 8 bytes in front of a pattern match
             if (lit >= 0) {
-                o[pos++] = (uint8_t)lit;
+                lbuf |= (uint64_t)(uint32_t)lit << (8u * lcnt);
+                ++lcnt; ++pos;
+                if (lcnt == 8u) { __builtin_memcpy(o + pos - 8u, &lbuf, 8); lbuf = 0; lcnt = 0; }
             } else if (clen != 0) {
                 if (small && have_pat && pos + 64u <= olen) {   // up to eight stores, no load: long runs in few iterations
                     const uint32_t step = (8u / cdist) * cdist;   // whole periods per store
@@ -346,6 +363,7 @@ __global__ __launch_bounds__(INF_NT) void inflate_members_kernel(const uint8_t *
             }
         }
         if (pend == 1u) __builtin_memcpy(o + ppos, &pw, 8);   // (left by a break)
+        lflush();
     }
     if (err == INF_OK && pos != olen) err = INF_ESIZE;
     if (err == INF_OK) {

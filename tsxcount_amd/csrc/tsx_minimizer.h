@@ -52,6 +52,13 @@ __host__ __device__ inline uint32_t mz_owner_of_kmer(uint64_t x, uint32_t k, uin
     return mz_owner(best, mbits, nranks);
 }
 
+// v_mul_u32_u24 (full rate; the compiler takes the quarter-rate 32-bit multiply where it cannot see the operands' width)
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, const uint4 *desc, uint64_t desc_cap,
                                                                     const unsigned long long *desc_cnt, uint32_t nregions,
                                                                     uint32_t nranks, uint4 *out, uint64_t out_cap,
@@ -61,24 +68,29 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
     __shared__ uint32_t s_base[MZ_MAX_RANKS];   // descriptions of this workgroup for the owner before this round
     __shared__ uint32_t s_fill[MZ_MAX_RANKS];   //   ... including it
     __shared__ uint32_t s_more[2];              // some lane has owners left for another round
+    __shared__ uint4 *s_list[MZ_MAX_RANKS];     // where each owner's list begins
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    if (tid < MZ_MAX_RANKS) { s_cnt[tid] = 0; s_fill[tid] = 0; }
+    if (tid < MZ_MAX_RANKS) { s_cnt[tid] = 0; s_fill[tid] = 0; s_list[tid] = out + (uint64_t)tid * out_cap; }
     if (tid < 2) s_more[tid] = 0;
     const uint32_t k = (uint32_t)p.k;
-    const uint32_t m = mz_m(k), mbits = 2u * m, mmask = (1u << mbits) - 1u, w = k - m + 1u, sh = 31u - mbits;
+    const uint32_t m = mz_m(k), mbits = 2u * m, w = k - m + 1u, sh = 31u - mbits;
     unsigned long long hacc = 0, lost = 0;   // hacc: homopolymer occurrences, 16 bits per base (a lane sees < 4096 strips)
     uint32_t round = 0;
     lds_barrier();
     // mz_key of the m-mer at `bit` of (lo, hi); pa: bit 2j of it = the m-mer at base j of lo starts or ends with AAA
     auto keyat = [&](uint32_t lo, uint32_t hi, uint32_t pa, uint32_t bit) -> uint32_t {
         const uint32_t x = __funnelshift_r(lo, hi, bit);   // (what lies above the m-mer only reaches product bits >= 2m)
-        const uint32_t v = ((__umul24(x, MZ_MULT) + MZ_SALT) & mmask) << sh;
-        return v | ((pa << (31u - bit)) & 0x80000000u);
+        const uint32_t v = (__umul24(x, MZ_MULT) + MZ_SALT) << sh;      // (bits from 2m on leave at the top or land on bit 31)
+        return (v & 0x7FFFFFFFu) | ((pa << (31u - bit)) & 0x80000000u);   // one v_bfi_b32
     };
     // place n of this workgroup's descriptions for owner o: its chunks are g, G + g, 2 G + g, ... of the list
-    auto place = [&](uint32_t n) -> unsigned long long {
-        return ((unsigned long long)(n / MZ_CHUNK) * G + g) * MZ_CHUNK + (n % MZ_CHUNK);
+    // (32-bit arithmetic: a list holds less than 2^32 descriptions -- a text is described in pieces below 4 GiB)
+    const uint32_t cap32 = (uint32_t)min(out_cap, (uint64_t)0xFFFFFFFFu);
+    auto place = [&](uint32_t n) -> uint32_t { return ((n / MZ_CHUNK) * G + g) * MZ_CHUNK + (n % MZ_CHUNK); };
+    auto put = [&](uint32_t o, uint32_t at, const uint4 v) {
+        if (at < cap32) s_list[o][at] = v;
+        else ++lost;
     };
     for (uint32_t r = g; r < nregions; r += G) {
         // share `part` of `nparts` of every region (a text is described once and split window by window: the exchange of
@@ -148,8 +160,8 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
                     uint32_t best = min(core, pre);
                     if (i < 15) best = min(best, suf[i]);
                     const uint32_t t = best >> sh;
-                    const uint32_t u = (__umul24(t, MZ_MULT2) >> 8) & 0xFFFFu;
-                    const uint32_t o = __umul24(u, nranks) >> 16;
+                    const uint32_t u = (mul24(t, MZ_MULT2) >> 8) & 0xFFFFu;   // (t < 2^23)
+                    const uint32_t o = mul24(u, nranks) >> 16;
                     P0 |= (o & 1u) << i;
                     P1 |= ((o >> 1) & 1u) << i;
                     P2 |= ((o >> 2) & 1u) << i;
@@ -221,14 +233,10 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
 #pragma unroll
                 for (int t = 0; t < MZ_ROUND; ++t)
                     if (mo[t]) {
-                        const unsigned long long at = place(s_base[oo[t]] + ix[t]);
-                        if (at < out_cap) out[(uint64_t)oo[t] * out_cap + at] = make_uint4(c0, c1, c2, mo[t]);
-                        else ++lost;
+                        put(oo[t], place(s_base[oo[t]] + ix[t]), make_uint4(c0, c1, c2, mo[t]));
                     }
                 if (xm) {
-                    const unsigned long long at = place(s_base[xo] + xi);
-                    if (at < out_cap) out[(uint64_t)xo * out_cap + at] = make_uint4(x0, x1, x2, xm);
-                    else ++lost;
+                    put(xo, place(s_base[xo] + xi), make_uint4(x0, x1, x2, xm));
                     xm = 0;
                 }
             } while (again);
@@ -239,8 +247,8 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
     for (uint32_t o = 0; o < nranks; ++o) {
         const uint32_t f = s_fill[o], end = (f + MZ_CHUNK - 1u) / MZ_CHUNK * MZ_CHUNK;
         for (uint32_t n = f + tid; n < end; n += MZ_NT) {
-            const unsigned long long at = place(n);
-            if (at < out_cap) out[(uint64_t)o * out_cap + at] = make_uint4(0, 0, 0, 0);
+            const uint32_t at = place(n);
+            if (at < cap32) s_list[o][at] = make_uint4(0, 0, 0, 0);
         }
     }
     if (tid < nranks) used[(uint64_t)tid * G + g] = (s_fill[tid] + MZ_CHUNK - 1u) / MZ_CHUNK;
