@@ -70,7 +70,12 @@ class TorchComm:
                 t.copy_(o[at:at + t.numel()].view(t.shape))
                 at += t.numel()
         else:
-            dist.all_to_all(list(outs), list(inps), group=self.group)
+            # (a pair with nothing to exchange -- both sides know: the sizes travelled before -- trades a dummy element
+            # instead of an empty tensor)
+            dev = next((t.device for t in list(outs) + list(inps) if t.is_cuda), None)
+            dummy = lambda t: torch.zeros((1,), dtype=t.dtype, device=dev if dev is not None else t.device)
+            dist.all_to_all([t if t.numel() else dummy(t) for t in outs], [t if t.numel() else dummy(t) for t in inps],
+                            group=self.group)
 
     def all_gather(self, out, inp):
         if self.gloo:
