@@ -434,7 +434,7 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
             const unsigned long long hb = __ballot(vm != 0u);
             if (hb) {
                 // (bit 16: the description before this one is the strip before this one in the text -- desc_owner_split_kernel)
-                const uint32_t nbr = (lane > 0 && ((hb >> (lane - 1)) & 1ULL)) ? 0x10000u : 0u;
+                const uint32_t nbr = (uint32_t)(((hb << 1) >> lane) & 1ULL) << 16;
                 if (vm) my[fill + (uint32_t)__builtin_popcountll(hb & lt)] = make_uint4(codes32[tid], codes32[tid + 1], codes32[tid + 2], vm | nbr);
                 fill += (uint32_t)__builtin_popcountll(hb);
             }
