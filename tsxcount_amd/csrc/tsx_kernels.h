@@ -339,10 +339,14 @@ __global__ __launch_bounds__(NT, WK == 1 ? 3 : 2) void count_fastq_kernel(TableP
 // DESCRIPTION of every strip that holds a k-mer start -- the 48 bases from its first position as 2-bit codes and
 // the 16 validity bits -- to its wave's region of a descriptor array; walk_part_kernel (tsx_partition.h) reads
 // descriptions, one per lane, every lane busy, and does first window + rolls + level-1 rings.  k <= 32.
+// HOMOUT (the minimizer exchange, 20 <= k <= 32, short descriptions): homopolymer k-mers leave the validity bits here and
+// are counted per base in hom_out[0..3] -- a strip that lies wholly in a poly-A tail is then not described at all.
+template <bool HOMOUT = false>
 __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const uint8_t *buf, uint64_t n, uint64_t own_end,
                                                            int head_open, const uint32_t *tile_line, uint64_t ntiles,
                                                            uint4 *desc, uint64_t desc_cap, unsigned long long *desc_cnt,
-                                                           unsigned long long *kmer_sum, int long_desc) {
+                                                           unsigned long long *kmer_sum, int long_desc,
+                                                           unsigned long long *hom_out = nullptr) {
     // long_desc (the exchange of a sharded run): FOUR neighbouring strips in one description of 32 bytes -- 96 bases
     // + 64 validity bits, half the bytes per start position (the 32 bases behind a strip's own 16 are shared).
     __shared__ uint64_t s_codes[(TILE + HALO) / 32 + 2];
@@ -354,6 +358,7 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
     if (tid < 3) s_nl[(TILE + HALO) / 64 + tid] = ~0ULL;
     if (tid < 2) s_codes[(TILE + HALO) / 32 + tid] = 0;
     unsigned long long added = 0;
+    unsigned long long hacc = 0;   // HOMOUT: homopolymer occurrences, 16 bits per base (flushed before a field can fill up)
     const uint32_t k = (uint32_t)p.k;
     const uint32_t region = blockIdx.x * (NT / 64) + wave;
     uint4 *my = desc + (uint64_t)region * desc_cap * (long_desc ? 2u : 1u);
@@ -428,8 +433,25 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
         const uint64_t g0 = base + s0;
         const uint32_t jmax = (start_lim > g0) ? (uint32_t)min((uint64_t)16, start_lim - g0) : 0u;
         const uint32_t nb1 = (p.line_mask & 2u) ? ~b1 : ~0u;
-        const uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);
+        uint32_t vm = ~(uint32_t)r & b0 & nb1 & ((1u << jmax) - 1u);
         added += (unsigned long long)__popc(vm);
+        if constexpr (HOMOUT) {
+            if (vm) {   // ne: bit 2j = base j differs from base j + 1; window i is a homopolymer iff none in i .. i + k - 2
+                const uint32_t c0 = codes32[tid], c1 = codes32[tid + 1], c2 = codes32[tid + 2];
+                const uint64_t lo = (uint64_t)c0 | ((uint64_t)c1 << 32), hi = c2;
+                const uint64_t xl = lo ^ ((lo >> 2) | (hi << 62)), xh = hi ^ (hi >> 2);
+                const uint64_t nl = (xl | (xl >> 1)) & 0x5555555555555555ULL, nh = (xh | (xh >> 1)) & 0x5555555555555555ULL;
+                const bool core_ok = ((nl >> 30) & ((1ULL << (2u * (k - 16u))) - 1ULL)) == 0ULL;
+                const uint32_t z = (uint32_t)nl & 0x3FFFFFFFu;
+                const uint32_t a = z ? ((31u - (uint32_t)__clz((int)z)) >> 1) + 1u : 0u;
+                const uint32_t s2 = 2u * (k - 1u);
+                const uint32_t zz = (uint32_t)((nl >> s2) | (nh << (64u - s2))) & 0x3FFFFFFFu;
+                const uint32_t b = zz ? (uint32_t)(__ffs((int)zz) - 1) >> 1 : 15u;
+                const uint32_t homm = (core_ok && a <= b) ? (((2u << b) - 1u) & ~((1u << a) - 1u)) & 0xFFFFu : 0u;
+                hacc += (unsigned long long)__popc(vm & homm) << (16u * ((c0 >> 30) & 3u));
+                vm &= ~homm;
+            }
+        }
         if (!long_desc) {
             const unsigned long long hb = __ballot(vm != 0u);
             if (hb) {
@@ -458,6 +480,14 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
         if (added) atomicAdd(&p.stats[ST_KMERS], added);
         if (added && kmer_sum) atomicAdd(kmer_sum, added);   // sharded runs: checked against what the walks keep
         desc_cnt[region] = fill;
+    }
+    if constexpr (HOMOUT) {   // (a lane sees one strip per tile of its workgroup: < 4096 strips of 16 for texts below 4 GiB)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            unsigned long long t = (hacc >> (16 * b)) & 0xFFFFULL;
+            for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d, 64);
+            if (lane == 0 && t && hom_out) atomicAdd(&hom_out[b], t);
+        }
     }
 }
 

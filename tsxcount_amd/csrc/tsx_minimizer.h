@@ -63,7 +63,8 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
                                                                     const unsigned long long *desc_cnt, uint32_t nregions,
                                                                     uint32_t nranks, uint4 *out, uint64_t out_cap,
                                                                     uint32_t *used, unsigned long long *hom_cnt, int merge,
-                                                                    uint32_t part, uint32_t nparts) {
+                                                                    uint32_t part, uint32_t nparts,
+                                                                    const unsigned long long *hom_pre) {
     __shared__ uint32_t s_cnt[MZ_MAX_RANKS];    // descriptions of this round per owner
     __shared__ uint32_t s_base[MZ_MAX_RANKS];   // descriptions of this workgroup for the owner before this round
     __shared__ uint32_t s_fill[MZ_MAX_RANKS];   //   ... including it
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
         for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd, 64);
         if (lane == 0 && t) atomicAdd(&hom_cnt[b], t);
     }
+    // (what strip_desc_kernel<true> took out when the text was described: reported with the first share)
+    if (hom_pre && part == 0u && blockIdx.x == 0 && tid < 4 && hom_pre[tid]) atomicAdd(&hom_cnt[tid], hom_pre[tid]);
     {
         unsigned long long t = lost;
         for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd, 64);

@@ -1077,12 +1077,18 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
         if (rcd != TSX_HIP_OK) return rcd;
         {   // region sizes | region offsets | total
             size_t have = m->desc_cnt_entries;
-            rcd = grow(st, m->d_desc_cnt, have, ((size_t)2 * gdr + 16) * 8 + (size_t)MZ_MAX_RANKS * m->cus * MZ_WG_PER_CU * 4);
+            rcd = grow(st, m->d_desc_cnt, have, ((size_t)2 * gdr + 16) * 8 + (size_t)MZ_MAX_RANKS * m->cus * MZ_WG_PER_CU * 4 + 64);
             m->desc_cnt_entries = have;
             if (rcd != TSX_HIP_OK) return rcd;
         }
         unsigned long long *d_cnt = m->d_desc_cnt, *d_offs = d_cnt + gdr, *d_tot = d_offs + gdr;
-        hipLaunchKernelGGL(strip_desc_kernel, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
+        if (dsc.owners) {   // homopolymers leave here already: counted in the four words behind the chunk counters
+            unsigned long long *d_hom = d_cnt + 2 * (size_t)gdr + 8 + ((size_t)MZ_MAX_RANKS * m->cus * MZ_WG_PER_CU + 1) / 2;
+            HIP_TRY(hipMemsetAsync(d_hom, 0, 32, st));
+            hipLaunchKernelGGL(strip_desc_kernel<true>, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
+                               (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum, 0, d_hom);
+        } else
+        hipLaunchKernelGGL(strip_desc_kernel<false>, dim3(gdd), dim3(NT), 0, st, m->p, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], dcap, d_cnt, dsc.sum, dsc.long_desc);
         if (dsc.owners) {   // owner = f(minimizer): the regions stay where they are, mini_split hands them out by owner
             HIP_TRY(hipGetLastError());
@@ -1179,7 +1185,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             const uint64_t desc_cap = ((ntiles + gd - 1) / gd) * (lng ? 16 : 64);
             rc = grow(st, m->d_buf[0], m->buf_bytes[0], (size_t)gdreg * desc_cap * (lng ? 32 : 16));
             if (rc != TSX_HIP_OK) return rc;
-            hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
+            hipLaunchKernelGGL(strip_desc_kernel<false>, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
                                (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[0], desc_cap, pl.c_log, (unsigned long long *)nullptr, lng);
             HIP_TRY(hipGetLastError());
             if (lds > ((size_t)80 << 10))   // 512 lists: one workgroup per CU, 1024 threads
@@ -1206,7 +1212,7 @@ static int run_fastq_piece(tsx_hip_map *m, const uint8_t *d_text, uint64_t n, ui
             m->desc_cnt_entries = have;
             if (rc != TSX_HIP_OK) return rc;
         }
-        hipLaunchKernelGGL(strip_desc_kernel, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
+        hipLaunchKernelGGL(strip_desc_kernel<false>, dim3(gd), dim3(NT), 0, st, pp, d_text, n, own_end, head_open,
                            (const uint32_t *)m->d_tile, ntiles, (uint4 *)m->d_buf[1], desc_cap, m->d_desc_cnt,
                            (unsigned long long *)nullptr, 0);
         HIP_TRY(hipGetLastError());
@@ -1540,7 +1546,8 @@ static int mini_split(tsx_hip_map *m, uint32_t part, uint32_t nparts, int nranks
     uint32_t *d_used = (uint32_t *)(d_cnt + 2 * (size_t)gdr + 8);   // chunks taken per (owner, workgroup)
     hipLaunchKernelGGL(desc_owner_split_kernel, dim3(gsp), dim3(MZ_NT), 0, st, m->p, (const uint4 *)m->d_buf[1], m->mz_dcap,
                        (const unsigned long long *)d_cnt, (uint32_t)gdr, (uint32_t)nranks, (uint4 *)dev_desc, (uint64_t)cap_per_owner,
-                       d_used, count + nranks, mz_merge, part, nparts);
+                       d_used, count + nranks, mz_merge, part, nparts,
+                       (const unsigned long long *)(d_cnt + 2 * (size_t)gdr + 8 + ((size_t)MZ_MAX_RANKS * m->cus * MZ_WG_PER_CU + 1) / 2));
     hipLaunchKernelGGL(desc_owner_finish_kernel, dim3(64, nranks), dim3(MZ_NT), 0, st, (const uint32_t *)d_used, (uint32_t)gsp,
                        (uint32_t)nranks, (uint4 *)dev_desc, (uint64_t)cap_per_owner, count, m->p.stats);
     HIP_TRY(hipGetLastError());
