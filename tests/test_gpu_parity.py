@@ -1011,6 +1011,74 @@ def test_minimizer_counting_world_8_in_one_process(T):
     assert sum(g[1]["count_sum"] for g in got) == int(counts.sum())
 
 
+def test_minimizer_entry_points_refuse_what_they_cannot_do(T):
+    """k outside 20..32, a shard of a slot-range table, more than 16 owners, a list capacity below what
+    tsx_hip_mini_part_capacity asks for, the walk flag on a sharded map: error codes, no launch.  A text described in
+    pieces and split in shares gives the same lists' content as one call (counts of valid starts)."""
+    import ctypes
+    import torch
+    from tsxcount_amd import synth
+    vp = ctypes.c_void_p
+    text = synth.fastq(71, 0, 300)
+    buf = torch.frombuffer(bytearray(text + b"\n" * 64), dtype=torch.uint8).to("cuda:0")
+    i64 = dict(dtype=torch.int64, device="cuda:0")
+    cnt = torch.zeros((20,), **i64)
+    emit = torch.zeros((2,), **i64)
+    small = T.TSXHashMapHIP(23, 0, 19)
+    assert not small._lib.tsx_hip_mini_supported(small.handle)
+    shard = T.TSXHashMapHIP(23, 0, 31, shard_bits=1, shard_index=0)
+    assert not shard._lib.tsx_hip_mini_supported(shard.handle)
+    dsc = torch.empty((2 * 4096,), **i64)
+    for bad in (small, shard):
+        assert bad._lib.tsx_hip_mini_describe_device(bad.handle, vp(buf.data_ptr()), len(text), 0, len(text), vp(emit.data_ptr()), None) == T.EINVAL
+        assert bad._lib.tsx_hip_mini_window_device(bad.handle, vp(buf.data_ptr()), len(text), 0, len(text), 2, vp(dsc.data_ptr()), 4096,
+                                                   vp(cnt.data_ptr()), vp(emit.data_ptr()), None) == T.EINVAL
+    assert shard._lib.tsx_hip_shard_walk_device(shard.handle, vp(dsc.data_ptr()), 16, 2, 0, 1, 1000, vp(emit[1:].data_ptr()), None) == T.EINVAL
+    m = T.TSXHashMapHIP(23, 0, 31)
+    L = m._lib
+    cap = ctypes.c_size_t(0)
+    assert L.tsx_hip_mini_capacity(m.handle, len(text), 17, ctypes.byref(cap)) == T.EINVAL
+    assert L.tsx_hip_mini_window_device(m.handle, vp(buf.data_ptr()), len(text), 0, len(text), 17, vp(dsc.data_ptr()), 4096,
+                                        vp(cnt.data_ptr()), vp(emit.data_ptr()), None) == T.EINVAL
+    assert L.tsx_hip_mini_window_device(m.handle, vp(buf.data_ptr()), len(text), 0, len(text), 4, vp(dsc.data_ptr()), 16,
+                                        vp(cnt.data_ptr()), vp(emit.data_ptr()), None) == T.ERANGE
+    assert L.tsx_hip_mini_describe_device(m.handle, vp(buf.data_ptr()), len(text), 8, 16, vp(emit.data_ptr()), None) == T.EINVAL   # offset not a multiple of 16
+    assert L.tsx_hip_mini_split_device(m.handle, 3, 3, 4, vp(dsc.data_ptr()), 4096, vp(cnt.data_ptr()), None) == T.EINVAL
+    # one call against describe + three shares: the same valid starts per owner, the same homopolymer totals
+    world = 4
+    assert L.tsx_hip_mini_part_capacity(m.handle, len(text) + 256, 1, ctypes.byref(cap)) == 0
+    c1 = cap.value
+    d1 = torch.empty((2 * c1 * world,), **i64)
+    assert L.tsx_hip_mini_window_device(m.handle, vp(buf.data_ptr()), len(text), 0, len(text), world, vp(d1.data_ptr()), c1,
+                                        vp(cnt.data_ptr()), vp(emit.data_ptr()), None) == 0
+    m.sync()
+    one = [int(x) for x in cnt[:world + 4].tolist()]
+
+    def starts(d, c, counts):   # valid start positions per owner
+        out = []
+        for o in range(world):
+            lst = d[2 * o * c:2 * (o * c + counts[o])].view(-1, 2)
+            w = (lst[:, 1] >> 32) & 0xFFFF
+            out.append(int(sum(bin(int(x)).count("1") for x in w.cpu().tolist())))
+        return out
+    s_one = starts(d1, c1, one)
+    assert L.tsx_hip_mini_part_capacity(m.handle, len(text) + 256, 3, ctypes.byref(cap)) == 0
+    c3 = cap.value
+    assert L.tsx_hip_mini_split_device(m.handle, 0, 3, world, vp(d1.data_ptr()), 16, vp(cnt.data_ptr()), None) == T.ERANGE
+    assert L.tsx_hip_mini_describe_device(m.handle, vp(buf.data_ptr()), len(text), 0, len(text), vp(emit.data_ptr()), None) == 0
+    s_three, hom = [0] * world, [0] * 4
+    d3 = torch.empty((2 * c3 * world,), **i64)
+    for part in range(3):
+        assert L.tsx_hip_mini_split_device(m.handle, part, 3, world, vp(d3.data_ptr()), c3, vp(cnt.data_ptr()), None) == 0
+        m.sync()
+        c = [int(x) for x in cnt[:world + 4].tolist()]
+        s_three = [a + b for a, b in zip(s_three, starts(d3, c3, c))]
+        hom = [a + b for a, b in zip(hom, c[world:])]
+    # (runs merged across strips may be cut differently at a share's border: the starts are the same, the descriptions need not be)
+    assert s_three == s_one and hom == one[world:] and sum(hom) > 0
+    assert int(emit[0].item()) == 2 * (sum(s_one) + sum(hom))
+
+
 @pytest.mark.parametrize("k,world", [(20, 2), (23, 7), (26, 16), (31, 8), (32, 5)])
 def test_minimizer_split_lists_hold_what_the_host_function_says(T, k, world):
     """desc_owner_split_kernel against tsx_hip_mini_owner_host: list o of a text's split, walked alone into an empty table,
