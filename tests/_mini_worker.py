@@ -40,8 +40,13 @@ def fasta_of(fastq_text):
 # (k, l, reads, windows, shape): l = 23: two radix levels, which the exchange needs; windows > 1: the text is cut inside lines and
 # records; k = 20 / 26 / 32: the ends of the supported range and the switch of the minimizer length (m = k - 15 below 26)
 CASES = ((31, 23, 1500, 3, "even"), (31, 23, 1500, 1, "skew"), (20, 23, 900, 2, "even"), (26, 23, 900, 4, "skew"),
-         (32, 23, 1200, 3, "fasta"), (27, 23, 600, 2, "even"))
+         (32, 23, 1200, 3, "fasta"), (27, 23, 600, 2, "even"), (31, 23, 1500, 2, "pieces"), (24, 23, 700, 1, "pieces"))
 for k, l, n_reads, windows, shape in CASES:
+    # "pieces": the text is described in several pieces (as a text above 2 GiB would be), cut at multiples of 4 KiB inside
+    # lines and records; ranks with uneven shards run the same number of pieces all the same
+    TD.MinimizerCounter.PIECE = (128 << 10) if shape == "pieces" else (2 << 30)
+    if shape == "pieces":
+        shape = "skew"
     first, cnt = shard(n_reads, shape)
     text = synth.fastq(67, first, cnt)
     whole_text = synth.fastq(67, 0, n_reads)
@@ -53,6 +58,7 @@ for k, l, n_reads, windows, shape in CASES:
     if shape == "fasta":
         m.set_record_lines(2)
     mc = TD.MinimizerCounter(m, len(text), windows=windows)
+    assert mc.windows == mc.pieces * mc.parts and (TD.MinimizerCounter.PIECE > (1 << 20) or mc.pieces > 1)
     torch.cuda.synchronize()
     whole = Oracle(k, 21, 4, seed=1)
     whole.count_fastq(whole_text, lines)
