@@ -365,6 +365,12 @@ tsx_hip_map *tsx_hip_group_map(tsx_hip_group *g, int rank);
 const char *tsx_hip_group_comm_name(const tsx_hip_group *g);   /* "rccl" or "copy" */
 const char *tsx_hip_group_last_error(void);
 int tsx_hip_group_set_record_lines(tsx_hip_group *g, int lines);
+/* exchange 0 (default): every GPU counts its shard into its own table, the tables are merged afterwards (any k);
+ * exchange 1: the minimizer exchange (20 <= k <= 32, at most 16 GPUs) -- strip descriptions travel to the GPU that owns
+ * their k-mers' minimizer BEFORE anything is built, nothing is merged (tsx_hip_group_merge is then a no-op), lookups go to
+ * tsx_hip_mini_owner_host(kmer). */
+int tsx_hip_group_set_exchange(tsx_hip_group *g, int mode);
+int tsx_hip_group_exchange(const tsx_hip_group *g);
 int tsx_hip_group_clear(tsx_hip_group *g);
 int tsx_hip_group_count_fastq_host(tsx_hip_group *g, const char *text, size_t n);
 int tsx_hip_group_merge(tsx_hip_group *g);

@@ -79,6 +79,41 @@ def test_group_counts_equal_the_oracle(ranks, k, l, s):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,k,l", [(2, 31, 23), (3, 20, 23), (8, 31, 23), (5, 32, 23), (1, 26, 23)])
+def test_group_minimizer_exchange_equals_the_oracle(ranks, k, l):
+    """The C++ group with the minimizer exchange (tsx_hip_group_set_exchange 1): record shards, every GPU describes and
+    splits its own, the lists travel (device copies behind a barrier here), every GPU walks what it owns, one build; the
+    homopolymer totals on their owners.  Every k-mer on the rank tsx_hip_mini_owner_host names and only there; a second
+    count doubles everything; FASTA; outside 20 <= k <= 32 the mode is refused."""
+    import tsxcount_amd as T
+    from oracle.oracle import Oracle
+    from tsxcount_amd import distributed as TD
+    from tsxcount_amd import synth
+    text = synth.fastq(93, 0, 700)
+    o = Oracle(k, 21, 4, seed=1)
+    n = o.count_fastq(text)
+    kmers, counts = o.dump()
+    owner = TD.owner_of(kmers, k, ranks)
+    g = T.TSXHashMapHIPGroup(ranks, l, 0, k, devices=[0] * ranks, comm="copy", exchange="mini")
+    for rep in (1, 2):
+        g.countFastq(text)
+        st = g.stats()
+        assert st["distinct"] == len(kmers) and st["count_sum"] == rep * n and st["insert_failures"] == 0
+        assert np.array_equal(g.getKmerCounts(kmers), rep * counts)
+        for r in range(ranks):
+            assert g.rank_stats(r)["distinct"] == int((owner == r).sum())
+    g.clear()
+    g.set_record_lines(2)
+    lines = text.split(b"\n")
+    fasta = b"".join(b">" + lines[i][1:] + b"\n" + lines[i + 1] + b"\n" for i in range(0, len(lines) - 1, 4))
+    g.countFastq(fasta)
+    assert np.array_equal(g.getKmerCounts(kmers), counts)
+    g.close()
+    with pytest.raises(T.TSXException):
+        T.TSXHashMapHIPGroup(2, 19, 0, 63, devices=[0, 0], comm="copy", exchange="mini")
+
+
+@pytest.mark.gpu
 def test_group_of_one_through_the_rccl_api():
     """ncclCommInitAll with the one GPU of this box, the merge's all-to-all as grouped ncclSend/ncclRecv from rank 0
     to rank 0: the RCCL leg of the C++ host through its API (N > 1 needs one GPU per rank)."""
@@ -96,12 +131,19 @@ def test_group_of_one_through_the_rccl_api():
     assert st["distinct"] == len(kmers) and st["count_sum"] == n
     assert np.array_equal(g.getKmerCounts(kmers), counts)
     g.close()
+    # the minimizer exchange's lists (pieces that are not neighbours in memory) through the same grouped send / recv
+    g = T.TSXHashMapHIPGroup(1, 23, 0, 31, comm="rccl", exchange="mini")
+    g.countFastq(text)
+    st = g.stats()
+    assert st["distinct"] == len(kmers) and st["count_sum"] == n
+    assert np.array_equal(g.getKmerCounts(kmers), counts)
+    g.close()
     with pytest.raises(T.TSXException):       # RCCL refuses two ranks on one GPU: reported, not attempted
         T.TSXHashMapHIPGroup(2, 19, 0, 31, devices=[0, 0], comm="rccl")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [["--gpus=2", "--comm=copy", "--devices=0,0"], ["--gpus=8", "--comm=copy", "--devices=0,0,0,0,0,0,0,0"],
+@pytest.mark.parametrize("args", [["--gpus=2", "--comm=copy", "--devices=0,0"], ["--gpus=8", "--comm=copy", "--devices=0,0,0,0,0,0,0,0", "--exchange=merge"],
                                   ["--gpus=1"]])
 def test_cli_gpus_check_passes_on_golden(tmp_path, args):
     """tsxCount --mode=HIP --gpus=N --check on the reference's own fixture: one command runs the job
@@ -117,4 +159,27 @@ def test_cli_gpus_check_passes_on_golden(tmp_path, args):
     out, err = p.stdout.decode(), p.stderr.decode()
     assert p.returncode == 0, out + err
     assert "Added a total of 194697 different kmers" in out and "total errors0" in out
-    assert "entries moved between GPUs by the merge" in err
+    assert "entries moved between GPUs by the merge" in err and "exchange: per-GPU tables merged" in err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,how", [(["--gpus=4", "--comm=copy", "--devices=0,0,0,0"], "minimizer"), (["--gpus=2", "--comm=copy", "--devices=0,0"], "merged"),
+                                      (["--gpus=3", "--comm=copy", "--devices=0,0,0", "--exchange=mini"], "minimizer")])
+def test_cli_gpus_exchange_choice(tmp_path, args, how):
+    """tsxCount --mode=HIP --gpus=N at k = 31: the minimizer exchange from 4 GPUs on (or on request), the table merge below;
+    the number of different k-mers it reports is the oracle's."""
+    from oracle.oracle import Oracle
+    from tsxcount_amd import synth
+    text = synth.fastq(95, 0, 600)
+    o = Oracle(31, 21, 4, seed=1)
+    o.count_fastq(text)
+    kmers, _ = o.dump()
+    fq = tmp_path / "reads.fastq"
+    fq.write_bytes(text)
+    exe = os.path.join(ROOT, "tsxcount_amd", "bin", "tsxCount")
+    p = subprocess.run([exe, "--input=%s" % fq, "--mode=HIP", "--k=31", "--l=23"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    out, err = p.stdout.decode(), p.stderr.decode()
+    assert p.returncode == 0, out + err
+    assert "Added a total of %d different kmers" % len(kmers) in out, out + err
+    assert ("exchange: minimizer owners" in err) == (how == "minimizer"), err

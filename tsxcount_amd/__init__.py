@@ -397,7 +397,7 @@ class TSXHashMapHIPGroup:
     into record shards, every GPU counts its own, the tables are merged (comm "rccl": RCCL, one GPU per rank; "copy":
     device copies, ranks may share a GPU), lookups go to the owner of each k-mer."""
 
-    def __init__(self, gpus, iL, iStorageBits, iK, hash_seed=1, devices=None, comm="rccl"):
+    def __init__(self, gpus, iL, iStorageBits, iK, hash_seed=1, devices=None, comm="rccl", exchange="merge"):
         self._lib = lib()
         self._h = ctypes.c_void_p()
         dv = (ctypes.c_int * gpus)(*devices) if devices is not None else None
@@ -405,6 +405,9 @@ class TSXHashMapHIPGroup:
                                             {"rccl": 0, "copy": 1}[comm])
         self._check(rc)
         self.k, self.wk, self.gpus = iK, key_limbs(iK), gpus
+        if exchange != "merge":      # "mini": the minimizer exchange (20 <= k <= 32), nothing is merged afterwards
+            self._check(self._lib.tsx_hip_group_set_exchange(self._h, {"merge": 0, "mini": 1}[exchange]))
+        self.exchange = exchange
 
     def _check(self, rc):
         if rc != OK:

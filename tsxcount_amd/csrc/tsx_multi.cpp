@@ -86,6 +86,7 @@ struct Slot {
     const uint64_t *send = nullptr;
     uint64_t *recv = nullptr;
     std::vector<size_t> send_off, recv_off;   // n + 1 entries each
+    std::vector<size_t> send_len;             // optional: words for peer p (then send_off[p] is only where they start)
     int device = 0;
     hipStream_t stream = nullptr;
 };
@@ -106,7 +107,7 @@ public:
         int rc = TSX_HIP_OK;
         for (size_t p = 0; p < slots.size() && rc == TSX_HIP_OK; ++p) {
             const Slot &src = slots[p];
-            const size_t words = src.send_off[rank + 1] - src.send_off[rank];
+            const size_t words = src.send_len.empty() ? src.send_off[rank + 1] - src.send_off[rank] : src.send_len[rank];
             if (words != me.recv_off[p + 1] - me.recv_off[p]) { g_multi_error = "exchange: split sizes disagree"; rc = TSX_HIP_EINVAL; break; }
             if (!words) continue;
             hipError_t e = (src.device == me.device)
@@ -131,7 +132,8 @@ public:
         const int n = (int)slots.size();
         int rc = api_->GroupStart();
         for (int p = 0; p < n && rc == 0; ++p) {
-            const size_t sw = me.send_off[p + 1] - me.send_off[p], rw = me.recv_off[p + 1] - me.recv_off[p];
+            const size_t sw = me.send_len.empty() ? me.send_off[p + 1] - me.send_off[p] : me.send_len[p];
+            const size_t rw = me.recv_off[p + 1] - me.recv_off[p];
             if (sw) rc = api_->Send(me.send + me.send_off[p], sw, NCCL_UINT64, p, comms_[rank], me.stream);
             if (rc == 0 && rw) rc = api_->Recv(me.recv + me.recv_off[p], rw, NCCL_UINT64, p, comms_[rank], me.stream);
         }
@@ -200,6 +202,8 @@ struct tsx_hip_group {
     Barrier *bar = nullptr;
     int lines_per_record = 4;
     int key_limbs = 1;
+    int k = 0;
+    int exchange = 0;                 // 0: per-GPU tables merged after the count; 1: minimizer exchange (tsx_minimizer.h)
     uint64_t exchanged_entries = 0;   // entries that changed GPU in the last merge
     double last_merge_ms = 0;
 };
@@ -254,6 +258,7 @@ extern "C" int tsx_hip_group_create(tsx_hip_group **out, int ngpus, const int *d
     }
     g->bar = new Barrier(ngpus);
     g->key_limbs = tsx_hip_key_limbs(k);
+    g->k = k;
     for (int r = 0; r < ngpus; ++r) {
         tsx_hip_map *m = nullptr;
         const int rc = tsx_hip_create(&m, k, l, storagebits, overflow_l, hash_seed, g->devices[r]);
@@ -375,9 +380,156 @@ static int merge_rank(tsx_hip_group *g, int r, std::vector<Slot> &slots, std::ve
     return rc;
 }
 
+// ---- the minimizer exchange from C++ (the Python form is distributed.MinimizerCounter) ----------
+// Every GPU describes its record shard once, splits the descriptions owner by owner in `parts` shares, the lists of a share
+// travel through the group's exchange, every GPU walks what it was sent into a table of its own; ONE level 2 + build at the
+// end, the homopolymer totals of all GPUs on their owners.  Nothing is merged afterwards: the tables are disjoint.
+extern "C" int tsx_hip_group_set_exchange(tsx_hip_group *g, int mode) {
+    if (!g || (mode != 0 && mode != 1)) return TSX_HIP_EINVAL;
+    if (mode == 1) {
+        if (g->n > 16) { g_multi_error = "minimizer exchange: at most 16 GPUs"; return TSX_HIP_EINVAL; }
+        for (tsx_hip_map *m : g->maps)
+            if (!tsx_hip_mini_supported(m)) { g_multi_error = "minimizer exchange: 20 <= k <= 32 and a table split by two radix levels"; return TSX_HIP_EINVAL; }
+    }
+    g->exchange = mode;
+    return TSX_HIP_OK;
+}
+extern "C" int tsx_hip_group_exchange(const tsx_hip_group *g) { return g ? g->exchange : 0; }
+
+namespace {
+struct MiniShared {
+    std::vector<std::vector<unsigned long long>> cnt;   // [rank][owner | 4 homopolymer totals] of the current share
+    std::vector<std::vector<unsigned long long>> hom;   // [rank][4] over all shares
+    std::vector<unsigned long long> described, walked;
+    std::vector<int> ok;
+    std::vector<Slot> slots;
+    explicit MiniShared(int n) : cnt(n, std::vector<unsigned long long>(n + 4, 0)), hom(n, std::vector<unsigned long long>(4, 0)),
+                                 described(n, 0), walked(n, 0), ok(n, 0), slots(n) {}
+};
+constexpr size_t MINI_PIECE = (size_t)2 << 30;     // bytes of text described at once
+constexpr size_t MINI_MIN_SHARE = (size_t)32 << 20;
+}  // namespace
+
+static int mini_rank(tsx_hip_group *g, int r, const char *text, size_t len, size_t max_len, MiniShared &sh) {
+    const int n = g->n;
+    tsx_hip_map *m = g->maps[r];
+    (void)hipSetDevice(g->devices[r]);
+    hipStream_t st = g->streams[r];
+    int rc = TSX_HIP_OK;
+    // the same rounds on every rank, whatever its own shard: pieces of the longest shard, shares of a piece
+    const size_t piece_bytes = std::min(MINI_PIECE, std::max<size_t>(4096, (max_len + 4095) & ~(size_t)4095));
+    const uint32_t pieces = (uint32_t)std::max<size_t>(1, (max_len + piece_bytes - 1) / piece_bytes);
+    const uint32_t parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, piece_bytes / MINI_MIN_SHARE));
+    const uint32_t rounds = pieces * parts;
+    size_t cap = 0;
+    (void)tsx_hip_mini_part_capacity(m, piece_bytes + 256, parts, &cap);
+    uint8_t *d_text = nullptr;
+    uint64_t *d_lists = nullptr, *d_recv = nullptr;
+    unsigned long long *d_cnt = nullptr, *d_emit = nullptr;
+    size_t recv_words = 0;
+    auto dmalloc = [&](void **p, size_t bytes) {
+        if (rc != TSX_HIP_OK) return;
+        if (hipMalloc(p, std::max<size_t>(bytes, 64)) != hipSuccess) { g_multi_error = "hipMalloc of an exchange buffer failed"; rc = TSX_HIP_ENOMEM; }
+    };
+    dmalloc((void **)&d_text, len + 256);
+    dmalloc((void **)&d_lists, (size_t)n * cap * 16);
+    dmalloc((void **)&d_cnt, ((size_t)n + 4) * 8);
+    dmalloc((void **)&d_emit, 16);
+    if (rc == TSX_HIP_OK && (hipMemcpyAsync(d_text, text, len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                             hipMemsetAsync(d_text + len, '\n', 256, st) != hipSuccess || hipMemsetAsync(d_emit, 0, 16, st) != hipSuccess))
+        rc = TSX_HIP_EHIP;
+    size_t est_total = 0, got_total = 0;
+    for (uint32_t round = 0; round < rounds; ++round) {
+        const uint32_t piece = round / parts, part = round % parts;
+        std::vector<unsigned long long> &mine = sh.cnt[r];
+        std::fill(mine.begin(), mine.end(), 0ULL);
+        if (rc == TSX_HIP_OK && part == 0) {
+            const size_t off = std::min((size_t)piece * piece_bytes, len & ~(size_t)15);
+            const size_t ln = (size_t)piece * piece_bytes < len ? std::min(piece_bytes, len - off) : 0;
+            rc = tsx_hip_mini_describe_device(m, d_text, len, off, ln, d_emit, st);
+        }
+        if (rc == TSX_HIP_OK) rc = tsx_hip_mini_split_device(m, part, parts, n, d_lists, cap, d_cnt, st);
+        if (rc == TSX_HIP_OK && (hipMemcpyAsync(mine.data(), d_cnt, ((size_t)n + 4) * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                                 hipStreamSynchronize(st) != hipSuccess))
+            rc = TSX_HIP_EHIP;
+        if (rc != TSX_HIP_OK) std::fill(mine.begin(), mine.end(), 0ULL);   // a failed rank offers nothing and still takes part
+        for (int o = 0; o < n; ++o) mine[o] = std::min<unsigned long long>(mine[o], cap);
+        for (int b = 0; b < 4; ++b) sh.hom[r][b] += mine[n + b];
+        g->bar->wait();                               // every rank's list sizes are on the table
+        Slot &sl = sh.slots[r];
+        sl.device = g->devices[r]; sl.stream = st;
+        sl.send_off.assign(n + 1, 0); sl.recv_off.assign(n + 1, 0); sl.send_len.assign(n, 0);
+        for (int p = 0; p < n; ++p) {
+            sl.send_off[p] = (size_t)p * cap * 2;
+            sl.send_len[p] = (size_t)sh.cnt[r][p] * 2;
+            sl.recv_off[p + 1] = sl.recv_off[p] + (size_t)sh.cnt[p][r] * 2;
+        }
+        const size_t got = sl.recv_off[n];            // words: two per description
+        if (rc == TSX_HIP_OK && got > recv_words) {
+            if (d_recv) { (void)hipStreamSynchronize(st); (void)hipFree(d_recv); d_recv = nullptr; }
+            recv_words = got + got / 4 + 4096;
+            dmalloc((void **)&d_recv, recv_words * 8);
+        }
+        sl.send = d_lists; sl.recv = d_recv;
+        sh.ok[r] = (rc == TSX_HIP_OK) ? 1 : 0;
+        g->bar->wait();
+        bool all_ok = true;
+        for (int p = 0; p < n; ++p) all_ok = all_ok && sh.ok[p];
+        if (!all_ok) {
+            if (rc == TSX_HIP_OK) { g_multi_error = "another rank failed before the exchange"; rc = TSX_HIP_EHIP; }
+            break;                                    // every rank sees the same flags: all leave together
+        }
+        rc = g->xch->all_to_all(r, sh.slots, *g->bar);
+        if (rc == TSX_HIP_OK) {
+            if (round == 0) est_total = (size_t)((double)std::max<size_t>(got / 2, 4096) * 10.0 * rounds * 1.2) + 65536;
+            rc = tsx_hip_shard_walk_device(m, d_recv, got / 2, 2, round, rounds, est_total, d_emit + 1, st);
+            got_total += got / 2;
+        }
+        // (a failure from here on is reported at the next round's agreement, or after the last one)
+    }
+    if (rc == TSX_HIP_OK && got_total) rc = tsx_hip_shard_build_l1_device(m, st);
+    unsigned long long em[2] = {0, 0};
+    if (rc == TSX_HIP_OK && (hipMemcpyAsync(em, d_emit, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess))
+        rc = TSX_HIP_EHIP;
+    sh.described[r] = em[0]; sh.walked[r] = em[1];
+    sh.ok[r] = (rc == TSX_HIP_OK) ? 1 : 0;
+    g->bar->wait();                                   // totals of all ranks
+    bool all_ok = true;
+    for (int p = 0; p < n; ++p) all_ok = all_ok && sh.ok[p];
+    if (all_ok) {
+        unsigned long long described = 0, walked = 0, hom[4] = {0, 0, 0, 0};
+        for (int p = 0; p < n; ++p) { described += sh.described[p]; walked += sh.walked[p]; for (int b = 0; b < 4; ++b) hom[b] += sh.hom[p][b]; }
+        if (described != walked + hom[0] + hom[1] + hom[2] + hom[3]) {
+            g_multi_error = "minimizer exchange: k-mer occurrences described != walked + homopolymers";
+            rc = TSX_HIP_EHIP;
+        }
+        for (int b = 0; b < 4 && rc == TSX_HIP_OK; ++b) {   // the homopolymer k-mers, on their owners, with the totals of all ranks
+            if (!hom[b]) continue;
+            uint64_t kmer = 0, cnt1 = hom[b];
+            for (int i = 0; i < g->k; ++i) kmer |= (uint64_t)b << (2 * i);
+            uint32_t owner = 0;
+            rc = tsx_hip_mini_owner_host(g->k, n, &kmer, 1, &owner);
+            if (rc == TSX_HIP_OK && (int)owner == r) rc = tsx_hip_add_kmers_host(m, &kmer, &cnt1, 1);
+        }
+    } else if (rc == TSX_HIP_OK) {
+        g_multi_error = "another rank failed";
+        rc = TSX_HIP_EHIP;
+    }
+    if (rc == TSX_HIP_OK) rc = tsx_hip_sync(m);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_text); (void)hipFree(d_lists); (void)hipFree(d_recv); (void)hipFree(d_cnt); (void)hipFree(d_emit);
+    if (r == 0) {
+        uint64_t moved = 0;   // (of the last share only: the sizes of earlier shares are gone)
+        for (int a = 0; a < n; ++a) for (int b = 0; b < n; ++b) if (a != b) moved += sh.cnt[a][b];
+        g->exchanged_entries = moved;
+    }
+    return rc;
+}
+
 // The tables hold per-GPU counts of the reads each GPU saw: merge them (any number of counts before one merge).
 extern "C" int tsx_hip_group_merge(tsx_hip_group *g) {
     if (!g) return TSX_HIP_EINVAL;
+    if (g->exchange == 1) return TSX_HIP_OK;   // minimizer exchange: the tables are disjoint as they are
     // (a group of one takes the same route: its entries travel from rank 0 to rank 0 through the collective)
     std::vector<Slot> slots(g->n), cslots(g->n);
     std::vector<std::vector<unsigned long long>> seg(g->n);
@@ -389,6 +541,12 @@ extern "C" int tsx_hip_group_merge(tsx_hip_group *g) {
 extern "C" int tsx_hip_group_count_fastq_host(tsx_hip_group *g, const char *text, size_t n) {
     if (!g || (!text && n)) return TSX_HIP_EINVAL;
     const std::vector<size_t> cuts = cut_records(text, n, g->n, g->lines_per_record);
+    if (g->exchange == 1) {
+        size_t max_len = 0;
+        for (int r = 0; r < g->n; ++r) max_len = std::max(max_len, cuts[r + 1] - cuts[r]);
+        MiniShared sh(g->n);
+        return run_ranks(g, [&](int r) { return mini_rank(g, r, text + cuts[r], cuts[r + 1] - cuts[r], max_len, sh); });
+    }
     std::vector<Slot> slots(g->n), cslots(g->n);
     std::vector<std::vector<unsigned long long>> seg(g->n);
     std::vector<int> ok(g->n, 0);
@@ -407,7 +565,14 @@ extern "C" int tsx_hip_group_get_counts_host(tsx_hip_group *g, const uint64_t *k
     std::vector<std::vector<uint64_t>> q(g->n);
     std::vector<std::vector<size_t>> where(g->n);
     for (size_t i = 0; i < n; ++i) {
-        const int o = tsx_hip_owner_host(g->maps[0], kmers + i * wk, g->n);
+        int o;
+        if (g->exchange == 1) {
+            uint32_t ow = 0;
+            if (tsx_hip_mini_owner_host(g->k, g->n, kmers + i * wk, 1, &ow) != TSX_HIP_OK) return TSX_HIP_EINVAL;
+            o = (int)ow;
+        } else {
+            o = tsx_hip_owner_host(g->maps[0], kmers + i * wk, g->n);
+        }
         if (o < 0 || o >= g->n) return TSX_HIP_EINVAL;
         q[o].insert(q[o].end(), kmers + i * wk, kmers + (i + 1) * wk);
         where[o].push_back(i);

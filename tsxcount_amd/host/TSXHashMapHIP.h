@@ -175,6 +175,9 @@ public:
     const tsx_hip_layout &getLayout() const { return m_oLayout; }
     int size() const { return tsx_hip_group_size(m_pGroup); }
     void setRecordLines(int iLines) { check(tsx_hip_group_set_record_lines(m_pGroup, iLines)); }
+    // 0: per-GPU tables merged after the count (any k); 1: the minimizer exchange (20 <= k <= 32, at most 16 GPUs)
+    void setExchange(int iMode) { check(tsx_hip_group_set_exchange(m_pGroup, iMode)); }
+    int exchange() const { return tsx_hip_group_exchange(m_pGroup); }
     void clear() { check(tsx_hip_group_clear(m_pGroup)); }
     // countKMers (main.cpp:104-218) over all GPUs + the merge of the tables
     void countFastq(const char *pText, size_t iBytes) { check(tsx_hip_group_count_fastq_host(m_pGroup, pText, iBytes)); }

@@ -28,6 +28,8 @@ struct arguments {
     bool group = false;           // --gpus given: the group path, even for one GPU (its merge then runs through RCCL with one rank)
     int gpus = 1;                 // --gpus N: reads shard across N GPUs, per-GPU tables merged over RCCL
     std::string comm = "rccl";    // --comm=rccl|copy (copy: device-to-device copies, ranks may share a GPU)
+    std::string exchange = "auto"; // --exchange=merge|mini|auto: tables merged after the count / minimizer exchange (20 <= k <= 32;
+                                  // auto: from 4 GPUs on where it applies)
     std::vector<int> devices;     // --devices=a,b,...: HIP ordinal per rank (default 0 .. N-1)
 };
 
@@ -41,7 +43,7 @@ static bool opt(const char *arg, const char *name, std::string &val) {
 static int usage() {
     std::cerr << "Usage: tsxCount --input=FASTQ|FASTA[.gz] [--k=K] [--l=L] [--s=STORAGE] [--mode=HIP] [--threads=T]\n"
                  "                [--check] [--checkabort] [--seed=S] [--device=D] [--format=fastq|fasta]\n"
-                 "                [--gpus=N [--comm=rccl|copy] [--devices=a,b,...]]\n"
+                 "                [--gpus=N [--comm=rccl|copy] [--devices=a,b,...] [--exchange=merge|mini|auto]]\n"
                  "Count k-mers on an MI355X. --check compares with FASTQ.<k>.count (kmer<TAB>count per line)."
               << std::endl;
     return 1;
@@ -172,6 +174,12 @@ static int run_group(const arguments &a) {
     TSXHashMapHIPGroup oGroup(a.gpus, a.devices.empty() ? nullptr : a.devices.data(), (uint8_t)a.l, (uint32_t)a.storagebits,
                               (uint16_t)a.k, a.seed, a.comm == "copy" ? 1 : 0);
     if (is_fasta(a)) { oGroup.setRecordLines(2); std::cerr << "Format=FASTA (2 lines per record)" << std::endl; }
+    // the minimizer exchange where it applies (auto: from 4 GPUs on, as bench.py); --exchange=mini insists on it
+    if (a.exchange == "mini" || (a.exchange == "auto" && a.gpus >= 4 && a.gpus <= 16 && a.k >= 20 && a.k <= 32)) {
+        try { oGroup.setExchange(1); }
+        catch (const TSXException &e) { if (a.exchange == "mini") throw; }
+    }
+    std::cerr << "exchange: " << (oGroup.exchange() == 1 ? "minimizer owners (strip descriptions travel, nothing is merged)" : "per-GPU tables merged") << std::endl;
     std::vector<char> owned;
     const char *text = nullptr;
     size_t n = 0;
@@ -186,7 +194,7 @@ static int run_group(const arguments &a) {
     oGroup.countFastq(text, n);
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (map) munmap(map, n);
-    std::cerr << "entries moved between GPUs by the merge: " << oGroup.exchangedEntries() << std::endl;
+    std::cerr << (oGroup.exchange() == 1 ? "descriptions moved between GPUs by the last share: " : "entries moved between GPUs by the merge: ") << oGroup.exchangedEntries() << std::endl;
     return report_and_check(oGroup, a, dt);
 }
 
@@ -207,6 +215,7 @@ int main(int argc, char *argv[]) {
         else if (opt(argv[i], "device", v)) a.device = atoi(v.c_str());
         else if (opt(argv[i], "gpus", v)) { a.gpus = atoi(v.c_str()); a.group = true; }
         else if (opt(argv[i], "comm", v)) a.comm = v;
+        else if (opt(argv[i], "exchange", v)) a.exchange = v;
         else if (opt(argv[i], "devices", v)) {
             for (size_t at = 0; at < v.size();) {
                 const size_t c = v.find(',', at);
@@ -235,6 +244,7 @@ int main(int argc, char *argv[]) {
         return 2;
     }
 
+    if (a.exchange != "merge" && a.exchange != "mini" && a.exchange != "auto") return usage();
     if (a.gpus < 1 || (a.comm != "rccl" && a.comm != "copy") || (!a.devices.empty() && (int)a.devices.size() != a.gpus)) return usage();
     try {
         if (a.group) return run_group(a);
