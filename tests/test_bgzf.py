@@ -79,7 +79,7 @@ def test_count_fastq_from_bgzf_equals_plain_text():
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,block", [(31, 65280), (127, 4000), (21, 700)])
 def test_bgzf_is_inflated_and_counted_in_batches(monkeypatch, k, block):
-    """A large .fastq.gz is inflated a batch of members at a time into two text buffers (1 GiB of text per batch by
+    """A large .fastq.gz is inflated a batch of members at a time into two text buffers (3 GiB of text per batch by
     default; the smallest batch, 128 KiB, here): lines, records and k-mers run across the batch seams, members of 4000
     and 700 bytes put dozens to hundreds of members into a batch.  Counts must equal those of the plain text, and the
     host copy of the inflated text zlib's."""

@@ -2016,7 +2016,8 @@ struct BgzfDev {
 // Members are inflated in BATCHES of at most this many bytes of text (whole members, at least one), so that a large
 // .fastq.gz needs two batch-sized text buffers instead of the whole text at once.  TSX_HIP_BGZF_BATCH: tests.
 static size_t bgzf_batch_bytes() {
-    size_t v = (size_t)1 << 30;
+    // (a launch of the inflate kernel takes as long as ONE member takes, 16 ms, whatever the number of members: few, big batches)
+    size_t v = (size_t)3 << 30;
     if (const char *e = getenv("TSX_HIP_BGZF_BATCH")) { const long long x = atoll(e); if (x > 0) v = (size_t)x; }
     return std::max<size_t>(v, (size_t)128 << 10);
 }
