@@ -442,14 +442,16 @@ __global__ __launch_bounds__(NT, 5) void strip_desc_kernel(TableParams p, const 
                 const uint64_t xl = lo ^ ((lo >> 2) | (hi << 62)), xh = hi ^ (hi >> 2);
                 const uint64_t nl = (xl | (xl >> 1)) & 0x5555555555555555ULL, nh = (xh | (xh >> 1)) & 0x5555555555555555ULL;
                 const bool core_ok = ((nl >> 30) & ((1ULL << (2u * (k - 16u))) - 1ULL)) == 0ULL;
+              if (core_ok) {   // (bases 15 .. k - 1, which every window of the strip holds, are one base: rare outside poly-A)
                 const uint32_t z = (uint32_t)nl & 0x3FFFFFFFu;
                 const uint32_t a = z ? ((31u - (uint32_t)__clz((int)z)) >> 1) + 1u : 0u;
                 const uint32_t s2 = 2u * (k - 1u);
                 const uint32_t zz = (uint32_t)((nl >> s2) | (nh << (64u - s2))) & 0x3FFFFFFFu;
                 const uint32_t b = zz ? (uint32_t)(__ffs((int)zz) - 1) >> 1 : 15u;
-                const uint32_t homm = (core_ok && a <= b) ? (((2u << b) - 1u) & ~((1u << a) - 1u)) & 0xFFFFu : 0u;
+                const uint32_t homm = (a <= b) ? (((2u << b) - 1u) & ~((1u << a) - 1u)) & 0xFFFFu : 0u;
                 hacc += (unsigned long long)__popc(vm & homm) << (16u * ((c0 >> 30) & 3u));
                 vm &= ~homm;
+              }
             }
         }
         if (!long_desc) {

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
     if (tid < 2) s_more[tid] = 0;
     const uint32_t k = (uint32_t)p.k;
     const uint32_t m = mz_m(k), mbits = 2u * m, w = k - m + 1u, sh = 31u - mbits;
-    unsigned long long hacc = 0, lost = 0;   // hacc: homopolymer occurrences, 16 bits per base (a lane sees < 4096 strips)
+    unsigned long long lost = 0;
     uint32_t round = 0;
     lds_barrier();
     // mz_key of the m-mer at `bit` of (lo, hi); pa: bit 2j of it = the m-mer at base j of lo starts or ends with AAA
@@ -109,23 +109,7 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
             uint32_t vm = d.w & 0xFFFFu;
             uint32_t P0 = 0, P1 = 0, P2 = 0, P3 = 0;
             if (__ballot(vm != 0u)) {
-                // ---- homopolymer k-mers leave the masks.  ne: bit 2j = base j differs from base j + 1; window i is a
-                //      homopolymer iff no such j in i .. i + k - 2 = (i .. 14) + the shared core (15 .. k - 2) + (k - 1 .. i + k - 2)
-                {
-                    const uint64_t lo = (uint64_t)c0 | ((uint64_t)c1 << 32), hi = c2;
-                    const uint64_t xl = lo ^ ((lo >> 2) | (hi << 62)), xh = hi ^ (hi >> 2);
-                    const uint64_t nl = (xl | (xl >> 1)) & 0x5555555555555555ULL, nh = (xh | (xh >> 1)) & 0x5555555555555555ULL;
-                    const bool core_ok = ((nl >> 30) & ((1ULL << (2u * (k - 16u))) - 1ULL)) == 0ULL;
-                    const uint32_t z = (uint32_t)nl & 0x3FFFFFFFu;
-                    const uint32_t a = z ? ((31u - (uint32_t)__clz((int)z)) >> 1) + 1u : 0u;
-                    const uint32_t s2 = 2u * (k - 1u);   // 38 .. 62
-                    const uint32_t zz = (uint32_t)((nl >> s2) | (nh << (64u - s2))) & 0x3FFFFFFFu;
-                    const uint32_t b = zz ? (uint32_t)(__ffs((int)zz) - 1) >> 1 : 15u;
-                    const uint32_t homm = (core_ok && a <= b) ? (((2u << b) - 1u) & ~((1u << a) - 1u)) & 0xFFFFu : 0u;
-                    const uint32_t hv = vm & homm;
-                    vm &= ~homm;
-                    hacc += (unsigned long long)__popc(hv) << (16u * ((c0 >> 30) & 3u));   // (all of them repeat base 15)
-                }
+                // (homopolymer k-mers left the validity bits when the text was described: strip_desc_kernel<true>)
                 // ---- the minimizer of each of the 16 windows: min over the m-mers i .. i + w - 1 of the strip =
                 //      min(suffix minimum of i .. 14, the shared core 15 .. w - 1, prefix minimum of w .. w + i - 1)
                 uint32_t pa0, pa1, pa2;   // bit 2j: the m-mer at base j starts or ends with AAA
@@ -253,12 +237,6 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
         }
     }
     if (tid < nranks) used[(uint64_t)tid * G + g] = (s_fill[tid] + MZ_CHUNK - 1u) / MZ_CHUNK;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        unsigned long long t = (hacc >> (16 * b)) & 0xFFFFULL;
-        for (int dd = 32; dd > 0; dd >>= 1) t += __shfl_down(t, dd, 64);
-        if (lane == 0 && t) atomicAdd(&hom_cnt[b], t);
-    }
     // (what strip_desc_kernel<true> took out when the text was described: reported with the first share)
     if (hom_pre && part == 0u && blockIdx.x == 0 && tid < 4 && hom_pre[tid]) atomicAdd(&hom_cnt[tid], hom_pre[tid]);
     {
