@@ -3,14 +3,17 @@
 // A table sharded by home-slot range (tsx_hip_shard_*) scatters consecutive k-mers of a read over all GPUs, so either every
 // key travels (8 B per occurrence) or every GPU rolls over every GPU's text (description exchange: N x the walk).  Here the
 // owner of a k-mer is a function of its MINIMIZER -- the m-mer of the k-mer with the smallest hash, m = min(11, k - 15) --
-// so runs of consecutive k-mers (about (k - m + 2) / 2 of them) share an owner: what travels is strip descriptions masked
-// per owner, 16 bytes per (strip, owner present in it), about 1.7 per strip of 16 starts at 8 GPUs, and every GPU walks only what it
-// owns into a table of its own (no slot-range split, no merge; a lookup goes to mz_owner_of_kmer(kmer)).
+// so runs of consecutive k-mers (12 on random sequence at k = 31) share an owner: what travels is strip descriptions masked
+// per owner, 16 bytes per (strip, owner present in it), about 1.65 per strip of 16 starts at 8 GPUs, and every GPU walks only
+// what it owns into a table of its own (no slot-range split, no merge; a lookup goes to mz_owner_of_kmer(kmer)).
 //
-//   desc_owner_split_kernel   strip descriptions (strip_desc_kernel's wave regions) -> one packed list per owner GPU
+//   desc_owner_split_kernel    strip descriptions (strip_desc_kernel<true>'s wave regions, a share of them per call) -> one
+//                              list per owner GPU, chunk by chunk
+//   desc_owner_finish_kernel   the lists' lengths; chunks no workgroup reached get descriptions without a valid start
 //
 // Homopolymer k-mers (poly-A tails: a sixth of all occurrences in the reference's synthetic reads, ONE key, one owner) are
-// taken out of the descriptions and counted per base here; the caller sends the four totals to their owners.
+// taken out of the descriptions and counted per base when the text is described (strip_desc_kernel<true>, tsx_kernels.h); the
+// first share reports the totals, the caller sends them to their owners.
 // 20 <= k <= 32 (the 16 windows of a strip share the m-mers 15 .. k - m of the strip: w = k - m + 1 >= 16).
 #pragma once
 #include "tsx_kernels.h"
