@@ -1,1 +1,4 @@
-for fq in 2 4 1 2; do echo "== flush_q $fq"; TSX_HIP_WALK_FLUSHQ=$fq timeout -k 10 200 python3 scripts/r3_shard_sim.py 8 2>&1 | grep "minimizer exchange\|plain one" | cut -c1-140; done
+B="--steps 10 --warmup 3 --no-cpu-baseline --check-reads 300"
+for v in 1 0 1 0; do echo "== FUSE_LINES=$v"; TSX_HIP_FUSE_LINES=$v timeout -k 10 300 python3 bench.py $B 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline());print(round(d['value']/1e9,2), round(d['ms_per_step'],3), d['config']['check'], d['roofline'].get('stage_ms'), d['roofline'].get('line_pass_ms'))"; done
