@@ -2148,26 +2148,45 @@ extern "C" int tsx_hip_count_fastq_bgzf_host(tsx_hip_map *m, const void *gz, siz
             g_last_error = "hipMalloc of a BGZF text buffer failed";
             rc = TSX_HIP_ENOMEM;
         }
+    // Batch i + 1 is copied to the device and inflated on a stream of its own while batch i is counted on the map's: the
+    // inflate stream only waits for the count that last read the buffer it is about to fill (two batches back).
+    hipStream_t st_inf = nullptr;
+    hipEvent_t counted[2] = {nullptr, nullptr};
+    if (rc == TSX_HIP_OK && d_txt[1] &&
+        (hipStreamCreateWithFlags(&st_inf, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&counted[0], hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&counted[1], hipEventDisableTiming) != hipSuccess)) {
+        g_last_error = "hipStreamCreate for the BGZF inflate stream failed";
+        rc = TSX_HIP_EHIP;
+    }
     size_t prev_len = 0;   // bytes of text in the previous batch's buffer, behind its head
     int b = 0;
-    for (size_t m0 = 0; m0 < nm && rc == TSX_HIP_OK; b ^= 1) {
+    size_t nbatch = 0;
+    for (size_t m0 = 0; m0 < nm && rc == TSX_HIP_OK; b ^= 1, ++nbatch) {
         const size_t m1 = bgzf_next_batch(ix, m0, batch), nb = bgzf_batch_text(ix, m0, m1);
         const bool first = (m0 == 0), last = (m1 == nm);
         uint8_t *buf = d_txt[b];
-        if (!first)   // the end of the text so far (it may reach back into the previous buffer's own head)
-            if (hipMemcpyAsync(buf, d_txt[b ^ 1] + prev_len, head, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
-        rc = inflate_batch((const uint8_t *)gz, n, ix, m0, m1, dv, buf + head, st);
+        hipStream_t sti = st_inf ? st_inf : st;   // (one batch in all: everything on the map's stream)
+        if (st_inf && nbatch >= 2 && hipStreamWaitEvent(st_inf, counted[b], 0) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        rc = inflate_batch((const uint8_t *)gz, n, ix, m0, m1, dv, buf + head, sti);   // (returns when the text is there)
         if (rc != TSX_HIP_OK) break;
+        if (!first) {   // the end of the text so far (it may reach back into the previous buffer's own head)
+            if (hipMemcpyAsync(buf, d_txt[b ^ 1] + prev_len, head, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+            // (the other buffer is free for the next batch's text only behind this copy as well)
+            if (st_inf && hipEventRecord(counted[b ^ 1], st) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
+        }
         if (hipMemsetAsync(buf + head + nb, '\n', 256, st) != hipSuccess) { rc = TSX_HIP_EHIP; break; }
         // piece: from `from` (16-byte aligned) to the end of this batch's text; it owns all start positions but the
         // last BGZF_PRE (they belong to the next piece, which sees them again behind its own head)
         const size_t from = first ? head : 16, len = head + nb - from;
         const size_t own = last ? len : (len > BGZF_PRE ? len - BGZF_PRE : 0);
         rc = run_fastq_piece(m, buf + from, len, own, first ? 0 : -1, st);
+        if (rc == TSX_HIP_OK && st_inf && hipEventRecord(counted[b], st) != hipSuccess) rc = TSX_HIP_EHIP;
         prev_len = nb;
         m0 = m1;
     }
     hipError_t e = hipStreamSynchronize(st);
+    if (st_inf) { (void)hipStreamSynchronize(st_inf); (void)hipStreamDestroy(st_inf); }
+    for (hipEvent_t ev : counted) if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(d_txt[0]); (void)hipFree(d_txt[1]);
     if (rc == TSX_HIP_OK && e != hipSuccess) { g_last_error = hipGetErrorString(e); rc = TSX_HIP_EHIP; }
     return rc;
