@@ -1079,6 +1079,33 @@ def test_minimizer_entry_points_refuse_what_they_cannot_do(T):
     assert int(emit[0].item()) == 2 * (sum(s_one) + sum(hom))
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_minimizer_exchange_fuzzed_record_structure(T, seed):
+    """The ragged texts (records of any length, empty lines, CR LF, N and lower case, homopolymer reads, a truncated last
+    record) through the minimizer exchange: the C++ group with 2..6 ranks on cuda:0 cuts the text into record shards (some
+    empty), every rank describes, splits, trades lists, walks; sum over ranks and the owner of every k-mer against the
+    oracle, for a k drawn per seed from 20..32."""
+    from oracle.oracle import Oracle
+    from tsxcount_amd import distributed as TD
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.integers(20, 33))
+    ranks = int(rng.integers(2, 7))
+    text = b"".join(_fuzz_text(rng) for _ in range(int(rng.integers(3, 10))))
+    o = Oracle(k, 20, 4, seed=1)
+    n = o.count_fastq(text)
+    kmers, counts = o.dump()
+    g = T.TSXHashMapHIPGroup(ranks, 23, 0, k, devices=[0] * ranks, comm="copy", exchange="mini")
+    g.countFastq(text)
+    st = g.stats()
+    assert st["count_sum"] == n and st["distinct"] == len(kmers) and st["insert_failures"] == 0
+    if len(kmers):
+        assert np.array_equal(g.getKmerCounts(kmers), counts)
+        owner = TD.owner_of(kmers, k, ranks)
+        for r in range(ranks):
+            assert g.rank_stats(r)["distinct"] == int((owner == r).sum())
+    g.close()
+
+
 @pytest.mark.parametrize("k,world", [(20, 2), (23, 7), (26, 16), (31, 8), (32, 5)])
 def test_minimizer_split_lists_hold_what_the_host_function_says(T, k, world):
     """desc_owner_split_kernel against tsx_hip_mini_owner_host: list o of a text's split, walked alone into an empty table,
