@@ -143,6 +143,8 @@ def lib():
     L.tsx_hip_group_get_counts_host.argtypes = [vp, u64p, sz, u64p]
     L.tsx_hip_group_get_stats.argtypes = [vp, ctypes.POINTER(Stats)]
     L.tsx_hip_group_exchanged_entries.argtypes = [vp]
+    L.tsx_hip_group_set_exchange.argtypes = [vp, ci]
+    L.tsx_hip_group_exchange.argtypes = [vp]
     L.tsx_hip_group_exchanged_entries.restype = u64
     L.tsx_hip_cut_records_host.argtypes = [ctypes.c_char_p, sz, ci, ci, ctypes.POINTER(sz)]
     _lib = L
