@@ -183,3 +183,82 @@ def test_minimizer_owner_function():
     import pytest
     with pytest.raises(T.TSXException):
         TD.owner_of(km[:4], 19, 8)      # k < 20: the 16 windows of a strip would not share a core
+
+
+def _lists_worker(rank, world, port, q):
+    """The minimizer exchange's collectives on CPU: every rank groups the k-mer occurrences of ITS reads by
+    owner = f(minimizer) (tsx_hip_mini_owner_host), the groups -- pieces that are not neighbours in memory, some empty --
+    travel through TorchComm.all_to_all_lists after their sizes through all_to_all, and the receiver counts what it got."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import tsxcount_amd as T
+    from tsxcount_amd import distributed as TD
+    from tsxcount_amd import synth
+    comm = TD.TorchComm()
+    k, n_reads = 31, 10
+    first, cnt = (0, 0) if rank == 0 else TD.shard_reads(n_reads, rank - 1, world - 1)   # rank 0 has no reads at all
+    text = synth.fastq(78, first, cnt)
+    lines = text.split(b"\n")
+    occ = [T.encode(s[i:i + k], k)[0] for s in lines[1::4] for i in range(len(s) - k + 1)]
+    occ = np.array(occ, dtype=np.uint64)
+    owner = TD.owner_of(occ, k, world) if len(occ) else np.zeros(0, dtype=np.uint32)
+    cap = len(occ) + 8      # the lists sit cap apart, as the split kernel leaves them
+    buf = torch.zeros((world * cap,), dtype=torch.int64)
+    sizes = []
+    for o in range(world):
+        mine = occ[owner == o].view(np.int64)
+        buf[o * cap:o * cap + len(mine)] = torch.from_numpy(mine.copy())
+        sizes.append(len(mine))
+    meta_in = torch.tensor(sizes, dtype=torch.int64).view(world, 1)
+    meta_out = torch.empty_like(meta_in)
+    comm.all_to_all(meta_out, meta_in)
+    rs = [int(x) for x in meta_out.view(-1).tolist()]
+    recv = torch.empty((sum(rs),), dtype=torch.int64)
+    outs, at = [], 0
+    for p in range(world):
+        outs.append(recv[at:at + rs[p]])
+        at += rs[p]
+    comm.all_to_all_lists(outs, [buf[o * cap:o * cap + sizes[o]] for o in range(world)])
+    got = recv.numpy().view(np.uint64)
+    assert len(got) == 0 or (TD.owner_of(got, k, world) == rank).all()
+    keys, counts = np.unique(got, return_counts=True)
+    q.put((rank, dict(zip(keys.tolist(), counts.tolist())), len(occ)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_minimizer_lists_exchange_on_cpu(world):
+    import tsxcount_amd as T
+    from tsxcount_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lists_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every occurrence arrived exactly once, on the owner of its k-mer
+    k = 31
+    text = synth.fastq(78, 0, 10)
+    lines = text.split(b"\n")
+    want = {}
+    for sq in lines[1::4]:
+        for i in range(len(sq) - k + 1):
+            key = int(T.encode(sq[i:i + k], k)[0])
+            want[key] = want.get(key, 0) + 1
+    merged = {}
+    for _, got, _ in res:
+        for key, c in got.items():
+            assert key not in merged, "a k-mer on two ranks"
+            merged[key] = c
+    assert merged == want
+    assert sum(n for _, _, n in res) == sum(want.values())
