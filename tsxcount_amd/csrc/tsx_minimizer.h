@@ -249,31 +249,68 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
     }
 }
 
-// Workgroup g of desc_owner_split_kernel filled chunks g, G + g, 2 G + g, ... of every list, used[o * G + g] of them: a list is
-// as long as its busiest workgroup made it, and the chunks the others did not reach carry descriptions without a valid start.
+// Workgroup g of desc_owner_split_kernel filled chunks g, G + g, 2 G + g, ... of every list, used[o * G + g] of them.  Rows
+// (a row = the G chunks j * G .. j * G + G - 1) below the least busy workgroup's count are full; the rows above it, up to the
+// busiest workgroup's count, are ragged -- about 5 % of a list would be chunks nobody reached.  One workgroup per list closes
+// them up: the R used chunks of the ragged rows come to lie in its first R places (the holes among those places take the used
+// chunks that lie behind them: as many of the one as of the other, sources and destinations apart), and the list is
+// min * G + R chunks long, every one of them used.  count[o] = its descriptions.  (Ragged rows beyond MZ_RAGGED places, or
+// more than 1024 workgroups: the holes get descriptions without a valid start instead, as in the first version.)
+constexpr uint32_t MZ_RAGGED = 8192;
 __global__ __launch_bounds__(MZ_NT) void desc_owner_finish_kernel(const uint32_t *used, uint32_t G, uint32_t nranks, uint4 *out,
                                                                   uint64_t out_cap, unsigned long long *count,
                                                                   unsigned long long *stats) {
-    __shared__ uint32_t s_max;
-    const uint32_t o = blockIdx.y, tid = threadIdx.x;
-    if (tid == 0) s_max = 0;
+    __shared__ uint32_t s_used[1024];
+    __shared__ uint16_t s_hole[MZ_RAGGED], s_move[MZ_RAGGED];
+    __shared__ uint32_t s_min, s_max, s_sum, s_nh, s_nm;
+    const uint32_t o = blockIdx.x, tid = threadIdx.x;
+    uint4 *list = out + (uint64_t)o * out_cap;
+    if (tid == 0) { s_min = 0xFFFFFFFFu; s_max = 0; s_sum = 0; s_nh = 0; s_nm = 0; }
     __syncthreads();
-    uint32_t mx = 0;
-    for (uint32_t g = tid; g < G; g += MZ_NT) mx = max(mx, used[(uint64_t)o * G + g]);
-    atomicMax(&s_max, mx);
+    {
+        uint32_t mn = 0xFFFFFFFFu, mx = 0, sum = 0;
+        for (uint32_t g = tid; g < G; g += MZ_NT) {
+            const uint32_t u = used[(uint64_t)o * G + g];
+            if (g < 1024u) s_used[g] = u;
+            mn = min(mn, u); mx = max(mx, u); sum += u;
+        }
+        atomicMin(&s_min, mn); atomicMax(&s_max, mx); atomicAdd(&s_sum, sum);
+    }
     __syncthreads();
-    mx = s_max;
-    unsigned long long total = (unsigned long long)mx * G * MZ_CHUNK;
+    const uint32_t mn = s_min, mx = s_max;
+    const uint32_t T = (mx - mn) * G;          // places of the ragged rows
+    const uint32_t R = s_sum - mn * G;         // used chunks among them
+    const bool close_up = G <= 1024u && T <= MZ_RAGGED;
+    unsigned long long total = (unsigned long long)(close_up ? mn * G + R : mx * G) * MZ_CHUNK;
     if (total > out_cap) {
-        if (blockIdx.x == 0 && tid == 0 && stats) atomicAdd(&stats[ST_FAIL], total - out_cap);
+        if (tid == 0 && stats) atomicAdd(&stats[ST_FAIL], total - out_cap);
         total = out_cap;
     }
-    if (blockIdx.x == 0 && tid == 0) count[o] = total;
-    for (uint32_t g = blockIdx.x; g < G; g += gridDim.x)
-        for (uint32_t j = used[(uint64_t)o * G + g] + tid / MZ_CHUNK; j < mx; j += MZ_NT / MZ_CHUNK) {
-            const unsigned long long at = ((unsigned long long)j * G + g) * MZ_CHUNK + tid % MZ_CHUNK;
-            if (at < out_cap) out[(uint64_t)o * out_cap + at] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) count[o] = total;
+    if (!close_up) {   // holes stay: descriptions without a valid start
+        for (uint32_t g = 0; g < G; ++g)
+            for (uint32_t j = used[(uint64_t)o * G + g] + tid / MZ_CHUNK; j < mx; j += MZ_NT / MZ_CHUNK) {
+                const unsigned long long at = ((unsigned long long)j * G + g) * MZ_CHUNK + tid % MZ_CHUNK;
+                if (at < out_cap) list[at] = make_uint4(0, 0, 0, 0);
+            }
+        return;
+    }
+    // place s of the ragged rows = chunk (mn + s / G) * G + s % G; used iff mn + s / G < used[s % G]
+    for (uint32_t s0 = 0; s0 < T; s0 += MZ_NT) {
+        const uint32_t sidx = s0 + tid;
+        if (sidx < T) {
+            const bool is_used = mn + sidx / G < s_used[sidx % G];
+            if (sidx < R && !is_used) s_hole[atomicAdd(&s_nh, 1u)] = (uint16_t)sidx;
+            if (sidx >= R && is_used) s_move[atomicAdd(&s_nm, 1u)] = (uint16_t)sidx;
         }
+    }
+    __syncthreads();
+    const uint32_t npair = min(s_nh, s_nm);    // (equal by construction)
+    const uint64_t base = (uint64_t)mn * G * MZ_CHUNK;
+    for (uint32_t pr = tid / MZ_CHUNK; pr < npair; pr += MZ_NT / MZ_CHUNK) {
+        const uint64_t src = base + (uint64_t)s_move[pr] * MZ_CHUNK + tid % MZ_CHUNK, dst = base + (uint64_t)s_hole[pr] * MZ_CHUNK + tid % MZ_CHUNK;
+        if (src < out_cap && dst < out_cap) list[dst] = list[src];
+    }
 }
 
 }  // namespace tsx

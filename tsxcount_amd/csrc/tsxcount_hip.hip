@@ -1548,7 +1548,7 @@ static int mini_split(tsx_hip_map *m, uint32_t part, uint32_t nparts, int nranks
                        (const unsigned long long *)d_cnt, (uint32_t)gdr, (uint32_t)nranks, (uint4 *)dev_desc, (uint64_t)cap_per_owner,
                        d_used, count + nranks, mz_merge, part, nparts,
                        (const unsigned long long *)(d_cnt + 2 * (size_t)gdr + 8 + ((size_t)MZ_MAX_RANKS * m->cus * MZ_WG_PER_CU + 1) / 2));
-    hipLaunchKernelGGL(desc_owner_finish_kernel, dim3(64, nranks), dim3(MZ_NT), 0, st, (const uint32_t *)d_used, (uint32_t)gsp,
+    hipLaunchKernelGGL(desc_owner_finish_kernel, dim3(nranks), dim3(MZ_NT), 0, st, (const uint32_t *)d_used, (uint32_t)gsp,
                        (uint32_t)nranks, (uint4 *)dev_desc, (uint64_t)cap_per_owner, count, m->p.stats);
     HIP_TRY(hipGetLastError());
     return TSX_HIP_OK;
