@@ -79,6 +79,8 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
     if (tid < 2) s_more[tid] = 0;
     const uint32_t k = (uint32_t)p.k;
     const uint32_t m = mz_m(k), mbits = 2u * m, w = k - m + 1u, sh = 31u - mbits;
+    const bool pow2 = (nranks & (nranks - 1u)) == 0u;
+    const uint32_t own_sh = 24u - (uint32_t)__builtin_ctz(nranks | 0x10000u);   // (power of two: log2)
     unsigned long long lost = 0;
     uint32_t round = 0;
     lds_barrier();
@@ -148,8 +150,9 @@ __global__ __launch_bounds__(MZ_NT) void desc_owner_split_kernel(TableParams p, 
                     uint32_t best = min(core, pre);
                     if (i < 15) best = min(best, suf[i]);
                     const uint32_t t = best >> sh;
-                    const uint32_t u = (mul24(t, MZ_MULT2) >> 8) & 0xFFFFu;   // (t < 2^23)
-                    const uint32_t o = mul24(u, nranks) >> 16;
+                    const uint32_t pr = mul24(t, MZ_MULT2);                  // (t < 2^23)
+                    // mz_owner: bits 8..23 of the product, scaled to the number of GPUs -- for a power of two its top bits
+                    const uint32_t o = pow2 ? (pr >> own_sh) & (nranks - 1u) : mul24((pr >> 8) & 0xFFFFu, nranks) >> 16;
                     P0 |= (o & 1u) << i;
                     P1 |= ((o >> 1) & 1u) << i;
                     P2 |= ((o >> 2) & 1u) << i;
