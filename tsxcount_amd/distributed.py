@@ -590,15 +590,15 @@ class MinimizerCounter:
     merged at the end, and a lookup goes to rank owner_of(kmers).  step() counts one device text of this rank's reads, cut
     into W windows:
 
-        compute stream   split(0) split(1) walk(0) split(2) walk(1) ...  walk(W-1)  level 2 + build + homopolymers
-        exchange stream        sizes(0) a2a(0)   sizes(1) a2a(1) ...
+        compute stream   describe split(0) .. split(W-1) walk(0) walk(1) ...  walk(W-1)  level 2 + build + homopolymers
+        exchange stream           sizes(0) a2a(0) sizes(1) a2a(1) ...
 
     split(i)  the text is described ONCE (tsx_hip_mini_describe_device: line pass + strip descriptions; texts above 2 GiB in
               pieces); tsx_hip_mini_split_device then hands out share i of the described strips as one packed list per owner
               rank (consecutive k-mers mostly share a minimizer, so a strip of 16 starts ends up in about 1.7 lists);
               homopolymer k-mers (poly-A tails: ONE key, one owner) are counted here instead and leave the descriptions
     sizes(i)  one small all-to-all: per pair {descriptions to come, the sender's status}; the only host wait of the window,
-              while split(i+1) is already queued
+              while the other shares' splits and the earlier walks are queued
     a2a(i)    grouped send / recv straight from the lists into window i's receive buffer (back to back by source rank)
     walk(i)   tsx_hip_shard_walk_device (flag 2): first window + rolls + radix level 1 over what arrived, every key kept
     build     ONE tsx_hip_shard_build_l1_device; the homopolymer totals (summed over ranks and windows in the step's final
@@ -631,15 +631,17 @@ class MinimizerCounter:
         _check(L.tsx_hip_mini_part_capacity(hmap.handle, self.piece_bytes + 256, self.parts, ctypes.byref(cap)))
         self.cap = cap.value
         i64 = dict(dtype=torch.int64, device=self.dev)
-        self.dsc = [torch.empty((2 * self.cap * self.world,), **i64) for _ in range(2)]     # [owner][cap] descriptions of 16 bytes
-        self.cnt = [torch.zeros((self.world + 4,), **i64) for _ in range(2)]                # list lengths, then homopolymers per base
+        # one set of lists per share of a piece: all shares are split before the first is walked (the exchange of share 0 then
+        # runs under the splits of the others, and every later one under the walks in front of it)
+        self.dsc = [torch.empty((2 * self.cap * self.world,), **i64) for _ in range(self.parts)]   # [owner][cap] descriptions of 16 bytes
+        self.cnt = [torch.zeros((self.world + 4,), **i64) for _ in range(self.parts)]              # list lengths, then homopolymers per base
         self.recv = [torch.zeros((0,), **i64) for _ in range(self.windows)]
         self.emit = torch.zeros((2,), **i64)      # [0] += occurrences described, [1] += occurrences walked
         self.hom = torch.zeros((4,), **i64)
         self.cs = torch.cuda.Stream(self.dev)
         self.xs = torch.cuda.Stream(self.dev)
-        self.ev_scan = [torch.cuda.Event() for _ in range(2)]
-        self.ev_exch = [torch.cuda.Event() for _ in range(2)]
+        self.ev_scan = [torch.cuda.Event() for _ in range(self.parts)]
+        self.ev_exch = [torch.cuda.Event() for _ in range(self.parts)]
         from . import encode
         import numpy as np
         self.hom_kmers = np.stack([encode("ACGT"[b] * hmap.k, hmap.k) for b in range(4)])
@@ -662,8 +664,8 @@ class MinimizerCounter:
         late = None      # a failure only this rank has seen: it stays in the collectives, all raise after the last all-reduce
 
         def split(i):
-            b = i & 1
             piece, part = divmod(i, self.parts)
+            b = part
             rc = OK
             if part == 0:     # the piece is described once; its shares follow window by window
                 off, ln = window_of(piece, nbytes, self.piece_bytes)
@@ -677,15 +679,16 @@ class MinimizerCounter:
             self.ev_scan[b].record(self.cs)
             return rc
 
-        rc_next = split(0)
         est_total, n_recv_total, n_sent = 0, 0, 0
+        rcs = []
         for i in range(nwin):
-            b = i & 1
-            rc_this = rc_next
-            if i + 1 < nwin:
-                if i >= 1:
-                    self.cs.wait_event(self.ev_exch[(i + 1) & 1])   # exchange i-1 has read the lists split(i+1) overwrites
-                rc_next = split(i + 1)                              # queued before the host waits for window i
+            b = i % self.parts
+            if b == 0:     # a new piece: described once, all its shares split (queued) before the host waits for the first
+                if i:
+                    for e in self.ev_exch:
+                        self.cs.wait_event(e)       # the last piece's exchanges have read the lists these splits overwrite
+                rcs = [split(i + j) for j in range(self.parts)]
+            rc_this = rcs[b]
             with torch.cuda.stream(self.xs):
                 self.xs.wait_event(self.ev_scan[b])
                 meta_in = torch.empty((world, 2), **i64)
