@@ -321,7 +321,8 @@ int tsx_hip_add_hashed_device(tsx_hip_map *m, const void *dev_keys, const void *
  * dev_desc + o * cap_per_owner * 16 bytes, cap_per_owner >= tsx_hip_mini_capacity(win_len); dev_counts[nranks + b] =
  * occurrences of the homopolymer k-mer of base b (A, C, G, T) in the window, which are NOT in the descriptions: the caller
  * adds the totals on the owner of each (tsx_hip_mini_owner_host, tsx_hip_add_kmers_device); dev_kmer_sum += all k-mer
- * occurrences of the window.  The receiver walks what it was sent with tsx_hip_shard_walk_device (long_desc = 2) and
+ * occurrences of the window.  The receiver walks what it was sent with tsx_hip_shard_walk_device (long_desc = 2: every key
+ * stays, the calls of a step -- slot 0 .. nslots - 1 -- append to ONE set of level-1 lists) and
  * builds with tsx_hip_shard_build_l1_device.  tsx_hip_mini_owner_host: the owner of each one-limb k-mer (lookups). */
 int tsx_hip_mini_supported(tsx_hip_map *m);
 int tsx_hip_mini_capacity(tsx_hip_map *m, size_t text_bytes, int nranks, size_t *descs_per_owner_out);
